@@ -1,0 +1,239 @@
+/*
+ * cuddle_hip.h — C ABI of libcuddle_hip.so: the MI355X (gfx950) implementation of
+ * CuddleDB's batched two-phase ANN query path
+ *   centroid routing -> binary-code (Hamming) / RaBitQ leaf scan -> fp32 rerank -> top-k.
+ *
+ * The reference (LLay/vectordb, Rust) has no FFI layer for this path; the boundary it
+ * exposes is the inherent method
+ *   ClusteredIndex::search(&self, query:&[f32], k, probes_per_level, rerank_factor)
+ *       -> Vec<(usize, f32)>                       src/index/hierarchical.rs:330-336
+ *   ClusteredIndexWithRaBitQ::search(...)          src/index/hierarchical_with_rabitq.rs:329-335
+ * Every entry point below names the reference function(s) it replaces. A Rust caller
+ * binds these with `extern "C"` declarations and links libcuddle_hip.so from its build.rs.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all arrays are row-major, little-endian;
+ *   - "host" entry points take host pointers and synchronise before returning;
+ *     "_device" entry points take device pointers + a hipStream_t (as void*) and are
+ *     asynchronous on that stream;
+ *   - every function returns a cuddle_status; cuddle_last_error() gives the message of the
+ *     last failure on the calling thread; the library never aborts the process
+ *     (the reference panics/aborts: hierarchical.rs:337,402; Cargo.toml:54);
+ *   - a handle may be used from several threads, but calls on ONE handle are serialised by
+ *     an internal mutex (they share the handle's workspace).
+ */
+#ifndef CUDDLE_HIP_H
+#define CUDDLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUDDLE_ABI_VERSION 1
+
+typedef enum cuddle_status {
+    CUDDLE_OK = 0,
+    CUDDLE_ERR_BAD_ARG = 1,   /* null pointer, k == 0, probes == 0, sizes out of supported range */
+    CUDDLE_ERR_BAD_DIM = 2,   /* query dimension != index dimension (reference: assert, hierarchical.rs:337) */
+    CUDDLE_ERR_HIP = 3,       /* a HIP runtime call failed */
+    CUDDLE_ERR_NO_DEVICE = 4, /* no gfx950 device visible */
+    CUDDLE_ERR_OOM = 5,       /* device or host allocation failed */
+    CUDDLE_ERR_BAD_INDEX = 6, /* index description is inconsistent (offsets not monotone, ids out of range ...) */
+    CUDDLE_ERR_UNSUPPORTED = 7 /* valid in the reference but outside this build's limits (documented per call) */
+} cuddle_status;
+
+/* DistanceMetric, src/distance/mod.rs:10-17. Returned distances follow distance() (:23-34):
+ * L2 -> sum (a-b)^2 (squared, no sqrt); DOT -> -sum a*b; COSINE -> 1 - dot/(|a||b|). */
+typedef enum cuddle_metric { CUDDLE_METRIC_L2 = 0, CUDDLE_METRIC_COSINE = 1, CUDDLE_METRIC_DOT = 2 } cuddle_metric;
+
+/* Phase-1 code family: BinaryQuantizer/BinaryVector (src/quantization/binary.rs:16-21,101-106)
+ * or RaBitQQuantizer/RaBitQVector (src/quantization/rabitq.rs:16-32). */
+typedef enum cuddle_code_kind { CUDDLE_CODE_BINARY = 0, CUDDLE_CODE_RABITQ = 1 } cuddle_code_kind;
+
+/* Search behaviour flags. Default (0) follows `search` (hierarchical.rs:330-431):
+ *   - levels with <= probes nodes keep all nodes in frontier order (:395-397);
+ *   - rerank_k = min(k*rerank_factor, 10000) (:447);
+ *   - levels with 4..=100 nodes are routed with L2^2 whatever the metric (:366-380).
+ * CUDDLE_SEARCH_STATS_VARIANT follows `search_with_stats` (:831-938) instead: every level is
+ * stably sorted, no 10000 cap (:927), routing always uses the index metric (:868-886). */
+#define CUDDLE_SEARCH_STATS_VARIANT 0x1u
+/* Record per-stage HIP events on the call's stream; read them with cuddle_stage_times(). */
+#define CUDDLE_SEARCH_TIME_STAGES 0x2u
+/* Route dense levels with the MFMA contraction + exact refinement (default) or force the
+ * all-exact VALU routing kernel (bit-identical results; used for A/B measurements). */
+#define CUDDLE_SEARCH_ROUTE_EXACT_ONLY 0x4u
+
+/* Flat description of one index (or one leaf shard of it). Mirrors ClusteredIndex's public
+ * fields nodes/root_ids/quantizer/binary_vectors/full_vectors (hierarchical.rs:51-70) and
+ * ClusterNode (:18-32), flattened:
+ *   node i: centroid = centroids[i*dim .. ), children = children[child_offsets[i] .. child_offsets[i+1]),
+ *           vector range (leaf-contiguous positions) = [vec_offsets[i], vec_offsets[i+1]).
+ *   A node without children is a leaf (hierarchical.rs:413). Internal nodes have an empty
+ *   vector range. Position p (0 <= p < n_vectors) is the p-th vector in "leaf-contiguous
+ *   order": leaves in node-id order, each leaf's vector_indices in stored order;
+ *   ids[p] is the reference's vector index (usize) of that vector.
+ * All per-vector arrays (ids, vectors, codes, rabitq_*) are given in leaf-contiguous order.
+ * The library copies everything to the device at create time; the caller keeps ownership. */
+typedef struct cuddle_index_desc {
+    uint32_t abi_version;  /* CUDDLE_ABI_VERSION */
+    uint32_t dim;          /* D */
+    uint32_t metric;       /* cuddle_metric */
+    uint32_t code_kind;    /* cuddle_code_kind */
+    uint32_t n_nodes;
+    uint32_t n_roots;
+    uint64_t n_vectors;    /* vectors stored in THIS shard (sum of leaf sizes) */
+    const float *centroids;         /* [n_nodes][dim]  ClusterNode::full_centroid */
+    const uint32_t *child_offsets;  /* [n_nodes+1] */
+    const uint32_t *children;       /* [child_offsets[n_nodes]] node ids */
+    const uint32_t *roots;          /* [n_roots]  ClusteredIndex::root_ids */
+    const uint64_t *vec_offsets;    /* [n_nodes+1] */
+    const uint64_t *ids;            /* [n_vectors] */
+    const float *vectors;           /* [n_vectors][dim]  MmapVectorStore rows (src/storage/mmap.rs:106-115) */
+    /* binary codes: BinaryVector::bits, ceil(dim/64) u64 words per vector, bit i of the
+     * vector at word i/64, bit i%64 (binary.rs:150-155); threshold = BinaryQuantizer::threshold */
+    const uint64_t *codes;          /* [n_vectors][ceil(dim/64)] or NULL for RABITQ */
+    float threshold;
+    uint32_t reserved0;
+    /* RaBitQ: rotation_matrix_t rows (rabitq.rs:20), RaBitQVector fields (:24-32) */
+    const float *rabitq_rot_t;      /* [dim][dim] or NULL */
+    const uint32_t *rabitq_codes;   /* [n_vectors][ceil(dim/32)] */
+    const float *rabitq_norm;       /* [n_vectors] */
+    const float *rabitq_ip_oo;      /* [n_vectors] */
+} cuddle_index_desc;
+
+typedef struct cuddle_index cuddle_index; /* opaque device-resident index + workspace */
+
+/* SearchStats (hierarchical.rs:36-45), summed over the batch plus per-query maxima. */
+typedef struct cuddle_stats {
+    uint64_t leaves_searched;        /* sum over queries */
+    uint64_t vectors_scanned;        /* sum over queries of candidates (vectors_scanned_binary) */
+    uint64_t vectors_reranked;       /* sum over queries (vectors_reranked_full) */
+    uint32_t max_candidates;         /* max over queries */
+    uint32_t max_leaves;             /* max over queries */
+    uint32_t tree_levels;            /* routing iterations executed */
+    uint32_t route_fallbacks;        /* queries x levels re-routed by the all-exact kernel */
+} cuddle_stats;
+
+/* Stage indices for cuddle_stage_times(). */
+enum {
+    CUDDLE_STAGE_QUANTIZE = 0, /* R1   query binarisation / RaBitQ query prep */
+    CUDDLE_STAGE_ROUTE = 1,    /* R2+R3 all tree levels */
+    CUDDLE_STAGE_SCAN = 2,     /* R4+R5 leaf scan + phase-1 selection */
+    CUDDLE_STAGE_RERANK = 3,   /* R6 */
+    CUDDLE_STAGE_TOPK = 4,     /* R7 */
+    CUDDLE_STAGE_COUNT = 5
+};
+
+/* ---- library ---------------------------------------------------------------------------- */
+uint32_t cuddle_abi_version(void);
+const char *cuddle_last_error(void);
+/* Number of visible HIP devices (0 when none); never fails. */
+int cuddle_device_count(void);
+
+/* ---- index life cycle ------------------------------------------------------------------- */
+/* Replaces ClusteredIndex::build's in-memory result as the thing `search` runs on
+ * (hierarchical.rs:163-173): uploads the flat arrays to device `device_id`, re-lays the codes
+ * out per leaf for coalesced streaming, precomputes centroid norms. */
+cuddle_status cuddle_index_create(const cuddle_index_desc *desc, int device_id, cuddle_index **out);
+void cuddle_index_destroy(cuddle_index *idx);
+/* Pre-size the handle's device workspace so that later searches with batch <= max_queries,
+ * k <= max_k, probes <= max_probes, k*rerank_factor <= max_rerank_k allocate nothing. */
+cuddle_status cuddle_index_reserve(cuddle_index *idx, uint32_t max_queries, uint32_t max_k,
+                                   uint32_t max_probes, uint32_t max_rerank_k);
+
+/* ---- the hot path ----------------------------------------------------------------------- */
+/* Batched `search` (hierarchical.rs:330-431 / hierarchical_with_rabitq.rs:329-427) for
+ * n_queries independent queries; row q of the outputs is what search(&queries[q], k, probes,
+ * rerank_factor) returns: ascending distance, out_count[q] <= k results (fewer when the
+ * reached leaves hold fewer vectors, hierarchical.rs:426-428,452-454). Unused slots hold
+ * id = UINT64_MAX, dist = +inf. Ties: phase-1 by (code distance, scan position), final by
+ * (distance, phase-1 order) — the stable-sort order of search_with_stats (:930-932).
+ * queries: [n_queries][dim] host; out_ids/out_dist: [n_queries][k] host; out_count: [n_queries]
+ * host or NULL; stats may be NULL. */
+cuddle_status cuddle_search_batch(cuddle_index *idx, const float *queries, uint32_t n_queries,
+                                  uint32_t dim, uint32_t k, uint32_t probes_per_level,
+                                  uint32_t rerank_factor, uint32_t flags, uint64_t *out_ids,
+                                  float *out_dist, uint32_t *out_count, cuddle_stats *stats);
+
+/* Same, with every pointer a device pointer on the index's device and the work enqueued on
+ * `stream` (a hipStream_t; NULL = the null stream). Returns after enqueueing; results are
+ * valid once the stream has been synchronised. d_out_count may be NULL. */
+cuddle_status cuddle_search_batch_device(cuddle_index *idx, const float *d_queries,
+                                         uint32_t n_queries, uint32_t dim, uint32_t k,
+                                         uint32_t probes_per_level, uint32_t rerank_factor,
+                                         uint32_t flags, uint64_t *d_out_ids, float *d_out_dist,
+                                         uint32_t *d_out_count, void *stream);
+
+/* Stats of the most recent search on this handle (synchronises the handle's last stream). */
+cuddle_status cuddle_last_stats(cuddle_index *idx, cuddle_stats *stats);
+/* Per-stage device time in milliseconds of the most recent search that ran with
+ * CUDDLE_SEARCH_TIME_STAGES; ms has CUDDLE_STAGE_COUNT entries. Synchronises. */
+cuddle_status cuddle_stage_times(cuddle_index *idx, float *ms);
+
+/* ---- stage entry points (host pointers; used by the parity tests) ----------------------- */
+/* distance() for n independent pairs (src/distance/mod.rs:23-34; accumulation order of
+ * simd_neon.rs:13-140): out[i] = distance(a[i], b[i], metric); a, b: [n][dim]. */
+cuddle_status cuddle_distance_pairs(const float *a, const float *b, uint64_t n, uint32_t dim,
+                                    uint32_t metric, float *out, int device_id);
+/* BinaryQuantizer::quantize (binary.rs:144-159) for n vectors: codes [n][ceil(dim/64)]. */
+cuddle_status cuddle_binary_quantize(const float *vectors, uint64_t n, uint32_t dim,
+                                     float threshold, uint64_t *codes, int device_id);
+/* hamming_distance (binary.rs:184-186) for n pairs of codes of `words` u64 each. */
+cuddle_status cuddle_hamming_pairs(const uint64_t *a, const uint64_t *b, uint64_t n,
+                                   uint32_t words, uint32_t *out, int device_id);
+/* BinaryQuantizer::from_vectors threshold (binary.rs:122-141): sequential f32 sum / count.
+ * Host computation (index-build side input of the path). */
+float cuddle_binary_threshold(const float *vectors, uint64_t n, uint32_t dim);
+
+/* Routing only (hierarchical.rs:349-423): for each query the accumulated leaf node ids in
+ * accumulation order. out_leaves: [n_queries][leaf_stride]; out_leaf_count: [n_queries].
+ * leaf_stride must be >= probes * tree_levels (cuddle_index_levels). */
+cuddle_status cuddle_route_batch(cuddle_index *idx, const float *queries, uint32_t n_queries,
+                                 uint32_t dim, uint32_t probes_per_level, uint32_t flags,
+                                 uint32_t *out_leaves, uint32_t leaf_stride,
+                                 uint32_t *out_leaf_count);
+/* collect_leaf_candidates (hierarchical.rs:618-641 / hierarchical_with_rabitq.rs:605-619)
+ * for given leaf lists: per query the (position, code distance) pairs in scan order.
+ * out_pos: [n_queries][cand_stride] leaf-contiguous positions (ids[pos] is the vector id);
+ * out_key: [n_queries][cand_stride] Hamming distance (BINARY, as u32) or the bit pattern of
+ * the estimated distance (RABITQ, reinterpret as float). */
+cuddle_status cuddle_scan_batch(cuddle_index *idx, const float *queries, uint32_t n_queries,
+                                uint32_t dim, const uint32_t *leaves, uint32_t leaf_stride,
+                                const uint32_t *leaf_count, uint64_t *out_pos, uint32_t *out_key,
+                                uint32_t cand_stride, uint32_t *out_cand_count);
+/* search_leaves (hierarchical.rs:439-464) for given leaf lists: scan + select_top_candidates
+ * (:645-655) + rerank_with_full_precision (:659-674) + finalize_results (:678-691). Also
+ * returns, when non-NULL, the phase-1 selection in phase-1 order: sel_pos/sel_key
+ * [n_queries][sel_stride] and sel_dist (reranked distance of each). */
+cuddle_status cuddle_search_leaves_batch(cuddle_index *idx, const float *queries,
+                                         uint32_t n_queries, uint32_t dim, const uint32_t *leaves,
+                                         uint32_t leaf_stride, const uint32_t *leaf_count,
+                                         uint32_t k, uint32_t rerank_factor, uint32_t flags,
+                                         uint64_t *out_ids, float *out_dist, uint32_t *out_count,
+                                         uint64_t *sel_pos, uint32_t *sel_key, float *sel_dist,
+                                         uint32_t sel_stride, uint32_t *sel_count);
+
+/* ---- introspection ---------------------------------------------------------------------- */
+uint32_t cuddle_index_dim(const cuddle_index *idx);
+uint32_t cuddle_index_levels(const cuddle_index *idx);       /* max tree depth + 1 */
+uint32_t cuddle_index_max_children(const cuddle_index *idx);
+uint32_t cuddle_index_max_leaf_size(const cuddle_index *idx);
+uint64_t cuddle_index_device_bytes(const cuddle_index *idx); /* index arrays + workspace */
+
+/* ---- multi-GPU merge -------------------------------------------------------------------- */
+/* Merge `n_lists` per-shard result lists (each [n_queries][k], ascending, padded with
+ * id = UINT64_MAX / +inf) into the global top-k per query, ties by (distance, list index,
+ * rank in list). Host computation on host pointers; the device path does the same merge on
+ * the all-gathered buffers (see vectordb_amd/sharded.py). lists_* are laid out
+ * [n_lists][n_queries][k]. */
+cuddle_status cuddle_merge_topk(const uint64_t *lists_ids, const float *lists_dist,
+                                uint32_t n_lists, uint32_t n_queries, uint32_t k,
+                                uint64_t *out_ids, float *out_dist, uint32_t *out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUDDLE_HIP_H */

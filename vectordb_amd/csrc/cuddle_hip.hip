@@ -1,0 +1,972 @@
+// cuddle_hip.hip — host side + C ABI of libcuddle_hip.so (see include/cuddle_hip.h).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see csrc/Makefile).
+// The library is self-contained HIP: no torch types, no CPU fallback. Without a visible GPU
+// every compute entry point returns CUDDLE_ERR_NO_DEVICE.
+#include "../../include/cuddle_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "cuddle_kernels.hpp"
+
+using namespace cuddle;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static cuddle_status fail(cuddle_status st, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(e__ == hipErrorOutOfMemory ? CUDDLE_ERR_OOM : CUDDLE_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e__), __FILE__, __LINE__);                           \
+    } while (0)
+
+#define ST_TRY(expr)                        \
+    do {                                    \
+        cuddle_status s__ = (expr);         \
+        if (s__ != CUDDLE_OK) return s__;   \
+    } while (0)
+
+static cuddle_status use_device(int device_id) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(CUDDLE_ERR_NO_DEVICE, "no HIP device visible");
+    }
+    if (device_id < 0 || device_id >= n) return fail(CUDDLE_ERR_BAD_ARG, "device_id %d out of range (0..%d)", device_id, n - 1);
+    HIP_TRY(hipSetDevice(device_id));
+    return CUDDLE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    cuddle_status ensure(size_t need) {
+        if (need <= bytes) return CUDDLE_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t alloc = (need + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc(&p, alloc);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(CUDDLE_ERR_OOM, "hipMalloc(%zu) failed: %s", alloc, hipGetErrorString(e));
+        }
+        bytes = alloc;
+        return CUDDLE_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct DevStats { // accumulated on device by stats_accum_kernel
+    unsigned long long leaves, scanned, reranked;
+    uint32_t max_cand, max_leaves, pad0, pad1;
+};
+
+// Work-space layout of one chunk of queries.
+struct Plan {
+    uint32_t qc = 0;        // queries per chunk
+    uint32_t k = 0, probes = 0;
+    uint32_t rerank_k = 0;
+    uint32_t fstride = 0;   // frontier capacity per query
+    uint32_t lstride = 0;   // leaf-list capacity per query
+    uint32_t cstride = 0;   // candidate capacity per query (spill buffer)
+    uint32_t sstride = 0;   // selection capacity per query
+    uint32_t dist_cap = 0;  // candidates kept in LDS by the scan kernel
+    size_t scan_lds = 0;
+    // carved pointers
+    uint64_t *qcodes = nullptr;
+    uint32_t *frontier[2] = {nullptr, nullptr}, *fcount[2] = {nullptr, nullptr};
+    float *fdist = nullptr;
+    uint32_t *leaves = nullptr, *lcount = nullptr;
+    uint16_t *gdist = nullptr;
+    uint32_t *sel_pos = nullptr, *sel_key = nullptr, *sel_count = nullptr, *cand_count = nullptr;
+    float *sel_dist = nullptr;
+    size_t bytes = 0;
+};
+
+struct cuddle_index {
+    int device = 0;
+    IndexDev dev{};
+    std::vector<void *> owned; // device allocations of the index arrays
+    uint64_t index_bytes = 0;
+    uint32_t n_levels = 0, max_children = 0, max_leaf = 0, n_leaves = 0;
+    float threshold = 0.f; // BinaryQuantizer::threshold
+    std::vector<uint32_t> level_width;
+    DevBuf ws;       // per-chunk work space (Plan)
+    DevBuf io;       // staging for the host entry points
+    DevStats *d_stats = nullptr;
+    std::mutex mu;
+    // stage timing of the last timed search
+    std::vector<hipEvent_t> events;
+    size_t events_used = 0;
+    bool timed = false;
+    hipStream_t last_stream = nullptr;
+    uint32_t last_levels = 0;
+    ~cuddle_index() {
+        for (void *p : owned) (void)hipFree(p);
+        ws.release();
+        io.release();
+        if (d_stats) (void)hipFree(d_stats);
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
+};
+
+static constexpr uint32_t kMaxChunk = 4096;
+static constexpr uint32_t kScanThreads = 512;
+static constexpr uint32_t kLdsDistCap = 24576; // u16 distances kept in LDS per query (48 KiB)
+
+template <class T>
+static cuddle_status upload(cuddle_index *ix, const T *src, size_t count, T **dst) {
+    *dst = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(CUDDLE_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    ix->owned.push_back(p);
+    ix->index_bytes += bytes;
+    if (count) HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<T *>(p);
+    return CUDDLE_OK;
+}
+
+template <class T>
+static cuddle_status dev_alloc(cuddle_index *ix, size_t count, T **dst) {
+    *dst = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(CUDDLE_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    ix->owned.push_back(p);
+    ix->index_bytes += bytes;
+    *dst = static_cast<T *>(p);
+    return CUDDLE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small kernels that live with the host code
+// ---------------------------------------------------------------------------------------------
+namespace cuddle {
+__global__ void stats_accum_kernel(const uint32_t *lcount, const uint32_t *cand_count, const uint32_t *sel_count,
+                                   uint32_t nq, DevStats *st) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    atomicAdd(&st->leaves, (unsigned long long)lcount[q]);
+    atomicAdd(&st->scanned, (unsigned long long)cand_count[q]);
+    atomicAdd(&st->reranked, (unsigned long long)sel_count[q]);
+    atomicMax(&st->max_cand, cand_count[q]);
+    atomicMax(&st->max_leaves, lcount[q]);
+}
+// Sum of squares of each centroid as a k-ordered fused-multiply-add chain (the form the f32 MFMA
+// contraction produces), used by the MFMA routing filter.
+__global__ void centroid_sqnorm_kernel(const float *c, uint32_t n, uint32_t dim, float *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (uint32_t j = 0; j < dim; ++j) s = __builtin_fmaf(c[(uint64_t)i * dim + j], c[(uint64_t)i * dim + j], s);
+    out[i] = s;
+}
+} // namespace cuddle
+
+// ---------------------------------------------------------------------------------------------
+// library
+// ---------------------------------------------------------------------------------------------
+extern "C" uint32_t cuddle_abi_version(void) { return CUDDLE_ABI_VERSION; }
+extern "C" const char *cuddle_last_error(void) { return g_last_error.c_str(); }
+extern "C" int cuddle_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// index creation
+// ---------------------------------------------------------------------------------------------
+static cuddle_status validate_desc(const cuddle_index_desc *d, std::vector<uint32_t> &depth, uint32_t &n_levels,
+                                   std::vector<uint32_t> &level_width) {
+    if (!d) return fail(CUDDLE_ERR_BAD_ARG, "desc is null");
+    if (d->abi_version != CUDDLE_ABI_VERSION) return fail(CUDDLE_ERR_BAD_ARG, "abi_version %u != %u", d->abi_version, CUDDLE_ABI_VERSION);
+    if (d->dim == 0 || d->dim > 32768) return fail(CUDDLE_ERR_UNSUPPORTED, "dim %u outside 1..32768", d->dim);
+    if (d->metric > CUDDLE_METRIC_DOT) return fail(CUDDLE_ERR_BAD_ARG, "unknown metric %u", d->metric);
+    if (d->code_kind > CUDDLE_CODE_RABITQ) return fail(CUDDLE_ERR_BAD_ARG, "unknown code_kind %u", d->code_kind);
+    if (d->n_nodes == 0 || d->n_roots == 0 || d->n_roots > d->n_nodes) return fail(CUDDLE_ERR_BAD_INDEX, "n_nodes/n_roots invalid");
+    if (d->n_vectors >= (1ull << 32)) return fail(CUDDLE_ERR_UNSUPPORTED, "n_vectors >= 2^32 per shard");
+    if (!d->centroids || !d->child_offsets || !d->roots || !d->vec_offsets) return fail(CUDDLE_ERR_BAD_ARG, "null tree array");
+    if (d->n_vectors && (!d->ids || !d->vectors)) return fail(CUDDLE_ERR_BAD_ARG, "null ids/vectors");
+    if (d->code_kind == CUDDLE_CODE_BINARY && d->n_vectors && !d->codes) return fail(CUDDLE_ERR_BAD_ARG, "null codes");
+    if (d->code_kind == CUDDLE_CODE_RABITQ && (!d->rabitq_rot_t || (d->n_vectors && (!d->rabitq_codes || !d->rabitq_norm || !d->rabitq_ip_oo))))
+        return fail(CUDDLE_ERR_BAD_ARG, "null RaBitQ array");
+    const uint32_t n = d->n_nodes;
+    if (d->child_offsets[0] != 0 || d->vec_offsets[0] != 0) return fail(CUDDLE_ERR_BAD_INDEX, "offsets must start at 0");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (d->child_offsets[i + 1] < d->child_offsets[i]) return fail(CUDDLE_ERR_BAD_INDEX, "child_offsets not monotone at %u", i);
+        if (d->vec_offsets[i + 1] < d->vec_offsets[i]) return fail(CUDDLE_ERR_BAD_INDEX, "vec_offsets not monotone at %u", i);
+        if (d->child_offsets[i + 1] > d->child_offsets[i] && d->vec_offsets[i + 1] > d->vec_offsets[i])
+            return fail(CUDDLE_ERR_BAD_INDEX, "node %u has both children and vectors", i);
+    }
+    if (d->vec_offsets[n] != d->n_vectors) return fail(CUDDLE_ERR_BAD_INDEX, "vec_offsets[n_nodes] != n_vectors");
+    if (d->child_offsets[n] && !d->children) return fail(CUDDLE_ERR_BAD_ARG, "null children");
+    // tree check + depths (breadth first from the roots)
+    depth.assign(n, UINT32_MAX);
+    std::vector<uint32_t> cur(d->roots, d->roots + d->n_roots), nxt;
+    uint32_t lvl = 0;
+    level_width.clear();
+    while (!cur.empty()) {
+        level_width.push_back((uint32_t)cur.size());
+        nxt.clear();
+        for (uint32_t v : cur) {
+            if (v >= n) return fail(CUDDLE_ERR_BAD_INDEX, "node id %u out of range", v);
+            if (depth[v] != UINT32_MAX) return fail(CUDDLE_ERR_BAD_INDEX, "node %u reachable twice (not a forest)", v);
+            depth[v] = lvl;
+            for (uint32_t c = d->child_offsets[v]; c < d->child_offsets[v + 1]; ++c) nxt.push_back(d->children[c]);
+        }
+        cur.swap(nxt);
+        if (++lvl > 64) return fail(CUDDLE_ERR_BAD_INDEX, "tree deeper than 64 levels");
+    }
+    n_levels = lvl;
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int device_id, cuddle_index **out) {
+    if (!out) return fail(CUDDLE_ERR_BAD_ARG, "out is null");
+    *out = nullptr;
+    std::vector<uint32_t> depth, level_width;
+    uint32_t n_levels = 0;
+    ST_TRY(validate_desc(d, depth, n_levels, level_width));
+    ST_TRY(use_device(device_id));
+    cuddle_index *ix = new (std::nothrow) cuddle_index();
+    if (!ix) return fail(CUDDLE_ERR_OOM, "host allocation failed");
+    struct Guard {
+        cuddle_index *p;
+        ~Guard() { delete p; }
+    } guard{ix};
+    ix->device = device_id;
+    ix->threshold = d->threshold;
+    ix->n_levels = n_levels;
+    ix->level_width = level_width;
+    const uint32_t n = d->n_nodes, D = d->dim, W = (D + 63) / 64, W32 = (D + 31) / 32;
+    const uint64_t N = d->n_vectors;
+    IndexDev &v = ix->dev;
+    v.dim = D; v.words = W; v.words32 = W32; v.metric = d->metric; v.code_kind = d->code_kind;
+    v.n_nodes = n; v.n_roots = d->n_roots; v.n_vectors = N;
+
+    // host-side derived arrays
+    std::vector<uint32_t> vec_off32(n + 1), code_off(n, 0), pos_leaf(N);
+    uint64_t code_units = 0; // 16-byte units
+    for (uint32_t i = 0; i <= n; ++i) vec_off32[i] = (uint32_t)d->vec_offsets[i];
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t cnt = vec_off32[i + 1] - vec_off32[i];
+        uint32_t cc = d->child_offsets[i + 1] - d->child_offsets[i];
+        ix->max_children = std::max(ix->max_children, cc);
+        if (cc == 0) {
+            ix->n_leaves++;
+            ix->max_leaf = std::max(ix->max_leaf, cnt);
+        }
+        code_off[i] = (uint32_t)code_units;
+        code_units += (uint64_t)(W / 2) * cnt + ((W & 1) ? (cnt + 1) / 2 : 0);
+        if (code_units >= (1ull << 32)) return fail(CUDDLE_ERR_UNSUPPORTED, "binary codes exceed 64 GiB per shard");
+        for (uint32_t p = vec_off32[i]; p < vec_off32[i + 1]; ++p) pos_leaf[p] = i;
+    }
+
+    float *centroids; uint32_t *child_off, *children, *roots, *vec_off, *coff; uint64_t *ids; float *vectors;
+    ST_TRY(upload(ix, d->centroids, (size_t)n * D, &centroids));
+    ST_TRY(upload(ix, d->child_offsets, (size_t)n + 1, &child_off));
+    ST_TRY(upload(ix, d->children, (size_t)d->child_offsets[n], &children));
+    ST_TRY(upload(ix, d->roots, (size_t)d->n_roots, &roots));
+    ST_TRY(upload(ix, vec_off32.data(), (size_t)n + 1, &vec_off));
+    ST_TRY(upload(ix, code_off.data(), (size_t)n, &coff));
+    ST_TRY(upload(ix, d->ids, (size_t)N, &ids));
+    ST_TRY(upload(ix, d->vectors, (size_t)N * D, &vectors));
+    v.centroids = centroids; v.child_off = child_off; v.children = children; v.roots = roots;
+    v.vec_off = vec_off; v.code_off = coff; v.ids = ids; v.vectors = vectors;
+
+    float *sqn;
+    ST_TRY(dev_alloc(ix, (size_t)n, &sqn));
+    hipLaunchKernelGGL(centroid_sqnorm_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, centroids, n, D, sqn);
+    v.centroid_sqnorm = sqn;
+
+    uint32_t *d_pos_leaf = nullptr;
+    if (N) {
+        HIP_TRY(hipMalloc((void **)&d_pos_leaf, N * sizeof(uint32_t)));
+        hipError_t e = hipMemcpy(d_pos_leaf, pos_leaf.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d_pos_leaf); return fail(CUDDLE_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e)); }
+    }
+    cuddle_status st = CUDDLE_OK;
+    if (d->code_kind == CUDDLE_CODE_BINARY) {
+        uint64_t *planar = nullptr, *raw = nullptr;
+        st = dev_alloc(ix, (size_t)code_units * 2, &planar);
+        if (st == CUDDLE_OK && N) {
+            hipError_t e = hipMalloc((void **)&raw, N * W * sizeof(uint64_t));
+            if (e != hipSuccess) st = fail(CUDDLE_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e));
+            if (st == CUDDLE_OK) {
+                (void)hipMemset(planar, 0, (size_t)code_units * 16);
+                e = hipMemcpy(raw, d->codes, N * W * sizeof(uint64_t), hipMemcpyHostToDevice);
+                if (e != hipSuccess) st = fail(CUDDLE_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+            }
+            if (st == CUDDLE_OK)
+                hipLaunchKernelGGL(relayout_codes_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, raw, planar,
+                                   vec_off, coff, d_pos_leaf, N, W);
+            (void)hipDeviceSynchronize();
+            if (raw) (void)hipFree(raw);
+        }
+        v.codes = reinterpret_cast<const uint4 *>(planar);
+    } else {
+        float *rot, *norm, *ipoo; uint32_t *rc = nullptr, *raw = nullptr;
+        st = upload(ix, d->rabitq_rot_t, (size_t)D * D, &rot);
+        if (st == CUDDLE_OK) st = upload(ix, d->rabitq_norm, (size_t)N, &norm);
+        if (st == CUDDLE_OK) st = upload(ix, d->rabitq_ip_oo, (size_t)N, &ipoo);
+        if (st == CUDDLE_OK) st = dev_alloc(ix, (size_t)N * W32, &rc);
+        if (st == CUDDLE_OK && N) {
+            hipError_t e = hipMalloc((void **)&raw, N * W32 * sizeof(uint32_t));
+            if (e != hipSuccess) st = fail(CUDDLE_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e));
+            if (st == CUDDLE_OK) {
+                e = hipMemcpy(raw, d->rabitq_codes, N * W32 * sizeof(uint32_t), hipMemcpyHostToDevice);
+                if (e != hipSuccess) st = fail(CUDDLE_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+            }
+            if (st == CUDDLE_OK)
+                hipLaunchKernelGGL(relayout_rabitq_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, raw, rc,
+                                   vec_off, d_pos_leaf, N, W32);
+            (void)hipDeviceSynchronize();
+            if (raw) (void)hipFree(raw);
+        }
+        if (st == CUDDLE_OK) { v.rot_t = rot; v.rq_norm = norm; v.rq_ipoo = ipoo; v.rq_codes = rc; }
+    }
+    if (d_pos_leaf) (void)hipFree(d_pos_leaf);
+    if (st != CUDDLE_OK) return st;
+    HIP_TRY(hipMalloc((void **)&ix->d_stats, sizeof(DevStats)));
+    HIP_TRY(hipMemset(ix->d_stats, 0, sizeof(DevStats)));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipGetLastError());
+    // kernels that may need more than 64 KiB of dynamic LDS
+    (void)hipFuncSetAttribute((const void *)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)selection_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)scan_select_hamming_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)scan_all_hamming_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    guard.p = nullptr;
+    *out = ix;
+    return CUDDLE_OK;
+}
+
+extern "C" void cuddle_index_destroy(cuddle_index *idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    (void)hipDeviceSynchronize();
+    delete idx;
+}
+
+extern "C" uint32_t cuddle_index_dim(const cuddle_index *idx) { return idx ? idx->dev.dim : 0; }
+extern "C" uint32_t cuddle_index_levels(const cuddle_index *idx) { return idx ? idx->n_levels : 0; }
+extern "C" uint32_t cuddle_index_max_children(const cuddle_index *idx) { return idx ? idx->max_children : 0; }
+extern "C" uint32_t cuddle_index_max_leaf_size(const cuddle_index *idx) { return idx ? idx->max_leaf : 0; }
+extern "C" uint64_t cuddle_index_device_bytes(const cuddle_index *idx) {
+    return idx ? idx->index_bytes + idx->ws.bytes + idx->io.bytes : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// planning the work space
+// ---------------------------------------------------------------------------------------------
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// lstride_min: lower bound for the leaf-list capacity (stage entry points pass their own lists).
+static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32_t probes, uint64_t rerank_k64,
+                               uint32_t lstride_min, Plan &pl) {
+    const IndexDev &v = ix->dev;
+    if (probes > kSortCap) {
+        // probes beyond every level's width behave as "keep / sort everything"; that is fine as
+        // long as no level is wider than the sort capacity.
+        uint32_t widest = 0;
+        for (uint32_t w : ix->level_width) widest = std::max(widest, w);
+        if (widest > kSortCap)
+            return fail(CUDDLE_ERR_UNSUPPORTED, "probes_per_level %u > %u with a level of %u nodes", probes, kSortCap, widest);
+        probes = kSortCap;
+    }
+    if (rerank_k64 > kMaxRerankK) return fail(CUDDLE_ERR_UNSUPPORTED, "k*rerank_factor %llu > %u", (unsigned long long)rerank_k64, kMaxRerankK);
+    pl.qc = std::min(nq, kMaxChunk);
+    pl.k = k;
+    pl.probes = probes;
+    pl.rerank_k = (uint32_t)rerank_k64;
+    // frontier bound: level 0 = roots; level l+1 <= min(width, min(probes, bound_l) * max_children)
+    uint64_t fb = v.n_roots, fmax = v.n_roots, lsum = 0;
+    for (uint32_t l = 0; l < ix->n_levels; ++l) {
+        uint64_t width = ix->level_width[l];
+        fb = std::min<uint64_t>(fb, width);
+        fmax = std::max(fmax, fb);
+        uint64_t sel = std::min<uint64_t>(fb, probes);
+        lsum += sel;
+        fb = sel * std::max<uint32_t>(ix->max_children, 1);
+    }
+    pl.fstride = (uint32_t)align_up(fmax, 4);
+    pl.lstride = (uint32_t)align_up(std::max<uint64_t>(std::min<uint64_t>(lsum, ix->n_leaves), std::max<uint32_t>(lstride_min, 1)), 4);
+    uint64_t cbound = std::min<uint64_t>((uint64_t)pl.lstride * ix->max_leaf, v.n_vectors);
+    pl.cstride = (uint32_t)align_up(std::max<uint64_t>(cbound, 8), 8);
+    pl.sstride = (uint32_t)align_up(std::max<uint64_t>(std::min<uint64_t>(pl.rerank_k, cbound), 4), 4);
+    pl.dist_cap = std::min(pl.cstride, kLdsDistCap);
+    pl.scan_lds = scan_lds_bytes(v.dim, v.words, pl.lstride, pl.dist_cap);
+    if (pl.scan_lds > 150 * 1024) return fail(CUDDLE_ERR_UNSUPPORTED, "leaf list of %u slots does not fit the scan kernel's LDS", pl.lstride);
+    // carve
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t qc = pl.qc;
+    size_t o_qcodes = carve(qc * std::max<uint32_t>(v.words, v.dim + 2) * 8); // binary: W u64; RaBitQ: dim+2 floats
+    size_t o_f0 = carve(qc * pl.fstride * 4), o_f1 = carve(qc * pl.fstride * 4);
+    size_t o_fc0 = carve(qc * 4), o_fc1 = carve(qc * 4);
+    size_t o_fd = carve(qc * pl.fstride * 4);
+    size_t o_lv = carve(qc * pl.lstride * 4), o_lc = carve(qc * 4);
+    size_t o_gd = carve(qc * (size_t)pl.cstride * 4); // u16 Hamming or f32 estimates
+    size_t o_sp = carve(qc * pl.sstride * 4), o_sk = carve(qc * pl.sstride * 4), o_sd = carve(qc * pl.sstride * 4);
+    size_t o_sc = carve(qc * 4), o_cc = carve(qc * 4);
+    pl.bytes = off;
+    ST_TRY(ix->ws.ensure(pl.bytes));
+    char *b = static_cast<char *>(ix->ws.p);
+    pl.qcodes = (uint64_t *)(b + o_qcodes);
+    pl.frontier[0] = (uint32_t *)(b + o_f0); pl.frontier[1] = (uint32_t *)(b + o_f1);
+    pl.fcount[0] = (uint32_t *)(b + o_fc0); pl.fcount[1] = (uint32_t *)(b + o_fc1);
+    pl.fdist = (float *)(b + o_fd);
+    pl.leaves = (uint32_t *)(b + o_lv); pl.lcount = (uint32_t *)(b + o_lc);
+    pl.gdist = (uint16_t *)(b + o_gd);
+    pl.sel_pos = (uint32_t *)(b + o_sp); pl.sel_key = (uint32_t *)(b + o_sk); pl.sel_dist = (float *)(b + o_sd);
+    pl.sel_count = (uint32_t *)(b + o_sc); pl.cand_count = (uint32_t *)(b + o_cc);
+    return CUDDLE_OK;
+}
+
+static cuddle_status rerank_k_of(uint32_t k, uint32_t rf, uint32_t flags, uint64_t &out) {
+    if (k == 0) return fail(CUDDLE_ERR_BAD_ARG, "k must be >= 1 (the reference underflows k-1, hierarchical.rs:651)");
+    if (rf == 0) return fail(CUDDLE_ERR_BAD_ARG, "rerank_factor must be >= 1");
+    uint64_t r = (uint64_t)k * rf;
+    if (!(flags & CUDDLE_SEARCH_STATS_VARIANT)) r = std::min<uint64_t>(r, 10000); // hierarchical.rs:447
+    out = r;
+    return CUDDLE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage launchers (device pointers, asynchronous on `s`)
+// ---------------------------------------------------------------------------------------------
+static void mark(cuddle_index *ix, hipStream_t s) {
+    if (!ix->timed) return;
+    if (ix->events_used == ix->events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        ix->events.push_back(e);
+    }
+    (void)hipEventRecord(ix->events[ix->events_used++], s);
+}
+
+
+static uint32_t host_next_pow2(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+static size_t route_select_lds_bytes(uint32_t scap) {
+    return (size_t)scap * 8 + 256 * 4 + 32 * 4 + 8 * 4 + 2 * ((size_t)scap + 1) * 4 + 16;
+}
+
+static cuddle_status launch_quantize(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, hipStream_t s) {
+    const IndexDev &v = ix->dev;
+    if (v.code_kind == CUDDLE_CODE_BINARY) {
+        uint64_t total = (uint64_t)nq * v.words;
+        hipLaunchKernelGGL(binary_quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dq, (uint64_t)nq,
+                           v.dim, v.words, ix->threshold, pl.qcodes);
+    } else {
+        return fail(CUDDLE_ERR_UNSUPPORTED, "RaBitQ query preparation is not built yet");
+    }
+    HIP_TRY(hipGetLastError());
+    return CUDDLE_OK;
+}
+
+// All tree levels (hierarchical.rs:349-423). Leaves end up in pl.leaves / pl.lcount.
+static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, uint32_t flags,
+                                  hipStream_t s) {
+    const IndexDev &v = ix->dev;
+    const uint32_t stats = (flags & CUDDLE_SEARCH_STATS_VARIANT) ? 1u : 0u;
+    hipLaunchKernelGGL(route_init_kernel, dim3((v.n_roots + 255) / 256, nq), dim3(256), 0, s, v.roots, v.n_roots,
+                       pl.frontier[0], pl.fstride, pl.fcount[0], pl.lcount, nq);
+    int cur = 0;
+    uint64_t fb = v.n_roots;
+    for (uint32_t l = 0; l < ix->n_levels; ++l) {
+        fb = std::min<uint64_t>(fb, ix->level_width[l]);
+        const uint32_t bound = (uint32_t)std::max<uint64_t>(fb, 1);
+        hipLaunchKernelGGL(route_dist_kernel, dim3((bound + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
+                           pl.frontier[cur], pl.fstride, pl.fcount[cur], pl.fdist, stats);
+        const uint32_t scap = std::min(kSortCap, host_next_pow2(bound));
+        hipLaunchKernelGGL(route_select_kernel, dim3(nq), dim3(256), route_select_lds_bytes(scap), s, v, pl.frontier[cur],
+                           pl.fstride, pl.fcount[cur], pl.fdist, pl.probes, stats, scap, pl.frontier[cur ^ 1],
+                           pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount);
+        cur ^= 1;
+        fb = std::min<uint64_t>(fb, pl.probes) * std::max<uint32_t>(ix->max_children, 1);
+    }
+    HIP_TRY(hipGetLastError());
+    return CUDDLE_OK;
+}
+
+// Scan + phase-1 selection for the leaf lists in pl.leaves / pl.lcount.
+static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32_t nq, hipStream_t s) {
+    const IndexDev &v = ix->dev;
+    if (v.code_kind != CUDDLE_CODE_BINARY) return fail(CUDDLE_ERR_UNSUPPORTED, "RaBitQ scan is not built yet");
+    hipLaunchKernelGGL(scan_select_hamming_kernel, dim3(nq), dim3(kScanThreads), pl.scan_lds, s, v, pl.qcodes, pl.leaves,
+                       pl.lstride, pl.lcount, pl.lstride, pl.rerank_k, pl.dist_cap, pl.gdist, pl.cstride, pl.sel_pos,
+                       pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count);
+    HIP_TRY(hipGetLastError());
+    return CUDDLE_OK;
+}
+
+static cuddle_status launch_rerank(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, hipStream_t s) {
+    const IndexDev &v = ix->dev;
+    hipLaunchKernelGGL(rerank_kernel, dim3((pl.sstride + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
+                       pl.sel_pos, pl.sstride, pl.sel_count, pl.sel_dist);
+    HIP_TRY(hipGetLastError());
+    return CUDDLE_OK;
+}
+
+static cuddle_status launch_topk(cuddle_index *ix, const Plan &pl, uint32_t nq, uint64_t *d_ids, float *d_dist,
+                                 uint32_t *d_count, hipStream_t s) {
+    const IndexDev &v = ix->dev;
+    size_t lds = (size_t)host_next_pow2(pl.sstride) * 8;
+    hipLaunchKernelGGL(topk_kernel, dim3(nq), dim3(256), lds, s, v, pl.sel_pos, pl.sel_key, pl.sel_dist, pl.sstride,
+                       pl.sel_count, pl.k, v.code_kind == CUDDLE_CODE_RABITQ ? 1u : 0u, d_ids, d_dist, d_count);
+    hipLaunchKernelGGL(stats_accum_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, pl.lcount, pl.cand_count,
+                       pl.sel_count, nq, ix->d_stats);
+    HIP_TRY(hipGetLastError());
+    return CUDDLE_OK;
+}
+
+// The whole path on device pointers; chunks the batch so the work space stays bounded.
+static cuddle_status search_device_locked(cuddle_index *ix, const float *dq, uint32_t nq, uint32_t dim, uint32_t k,
+                                          uint32_t probes, uint32_t rf, uint32_t flags, uint64_t *d_ids, float *d_dist,
+                                          uint32_t *d_count, hipStream_t s) {
+    if (!dq || !d_ids || !d_dist) return fail(CUDDLE_ERR_BAD_ARG, "null query or output pointer");
+    if (dim != ix->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, ix->dev.dim);
+    if (probes == 0) return fail(CUDDLE_ERR_BAD_ARG, "probes_per_level must be >= 1");
+    uint64_t rerank_k;
+    ST_TRY(rerank_k_of(k, rf, flags, rerank_k));
+    ix->timed = (flags & CUDDLE_SEARCH_TIME_STAGES) != 0;
+    ix->events_used = 0;
+    ix->last_stream = s;
+    ix->last_levels = ix->n_levels;
+    HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
+    if (nq == 0) return CUDDLE_OK;
+    Plan pl;
+    ST_TRY(make_plan(ix, nq, k, probes, rerank_k, 0, pl));
+    for (uint32_t q0 = 0; q0 < nq; q0 += pl.qc) {
+        const uint32_t qc = std::min(pl.qc, nq - q0);
+        const float *q = dq + (uint64_t)q0 * dim;
+        mark(ix, s);
+        ST_TRY(launch_quantize(ix, pl, q, qc, s));
+        mark(ix, s);
+        ST_TRY(launch_route(ix, pl, q, qc, flags, s));
+        mark(ix, s);
+        ST_TRY(launch_scan_select(ix, pl, qc, s));
+        mark(ix, s);
+        ST_TRY(launch_rerank(ix, pl, q, qc, s));
+        mark(ix, s);
+        ST_TRY(launch_topk(ix, pl, qc, d_ids + (uint64_t)q0 * k, d_dist + (uint64_t)q0 * k, d_count ? d_count + q0 : nullptr, s));
+        mark(ix, s);
+    }
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_search_batch_device(cuddle_index *idx, const float *d_queries, uint32_t n_queries,
+                                                    uint32_t dim, uint32_t k, uint32_t probes_per_level,
+                                                    uint32_t rerank_factor, uint32_t flags, uint64_t *d_out_ids,
+                                                    float *d_out_dist, uint32_t *d_out_count, void *stream) {
+    if (!idx) return fail(CUDDLE_ERR_BAD_ARG, "index is null");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    return search_device_locked(idx, d_queries, n_queries, dim, k, probes_per_level, rerank_factor, flags, d_out_ids,
+                                d_out_dist, d_out_count, static_cast<hipStream_t>(stream));
+}
+
+static cuddle_status read_stats(cuddle_index *ix, cuddle_stats *st) {
+    DevStats h;
+    HIP_TRY(hipStreamSynchronize(ix->last_stream));
+    HIP_TRY(hipMemcpy(&h, ix->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    st->leaves_searched = h.leaves;
+    st->vectors_scanned = h.scanned;
+    st->vectors_reranked = h.reranked;
+    st->max_candidates = h.max_cand;
+    st->max_leaves = h.max_leaves;
+    st->tree_levels = ix->last_levels;
+    st->route_fallbacks = 0;
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_last_stats(cuddle_index *idx, cuddle_stats *stats) {
+    if (!idx || !stats) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    return read_stats(idx, stats);
+}
+
+extern "C" cuddle_status cuddle_stage_times(cuddle_index *idx, float *ms) {
+    if (!idx || !ms) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    for (int i = 0; i < CUDDLE_STAGE_COUNT; ++i) ms[i] = 0.f;
+    if (idx->events_used == 0) return CUDDLE_OK;
+    HIP_TRY(hipEventSynchronize(idx->events[idx->events_used - 1]));
+    const size_t per = CUDDLE_STAGE_COUNT + 1;
+    for (size_t c = 0; c + per <= idx->events_used; c += per)
+        for (int sidx = 0; sidx < CUDDLE_STAGE_COUNT; ++sidx) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, idx->events[c + sidx], idx->events[c + sidx + 1]));
+            ms[sidx] += t;
+        }
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_index_reserve(cuddle_index *idx, uint32_t max_queries, uint32_t max_k,
+                                              uint32_t max_probes, uint32_t max_rerank_k) {
+    if (!idx) return fail(CUDDLE_ERR_BAD_ARG, "index is null");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    Plan pl;
+    return make_plan(idx, std::max(max_queries, 1u), std::max(max_k, 1u), std::max(max_probes, 1u),
+                     std::max<uint64_t>(max_rerank_k, 1), 0, pl);
+}
+
+// Staging buffer of the host entry points: [queries][ids][dist][count] for one call.
+struct HostIO {
+    float *q = nullptr;
+    uint64_t *ids = nullptr;
+    float *dist = nullptr;
+    uint32_t *count = nullptr;
+};
+
+static cuddle_status carve_io(cuddle_index *ix, uint32_t nq, uint32_t dim, uint32_t k, size_t extra, HostIO &io, char **extra_p) {
+    size_t o_q = 0, o_ids = align_up(o_q + (size_t)nq * dim * 4, 256), o_dist = align_up(o_ids + (size_t)nq * k * 8, 256);
+    size_t o_cnt = align_up(o_dist + (size_t)nq * k * 4, 256), o_extra = align_up(o_cnt + (size_t)nq * 4, 256);
+    ST_TRY(ix->io.ensure(o_extra + extra + 256));
+    char *b = static_cast<char *>(ix->io.p);
+    io.q = (float *)(b + o_q);
+    io.ids = (uint64_t *)(b + o_ids);
+    io.dist = (float *)(b + o_dist);
+    io.count = (uint32_t *)(b + o_cnt);
+    if (extra_p) *extra_p = b + o_extra;
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_search_batch(cuddle_index *idx, const float *queries, uint32_t n_queries, uint32_t dim,
+                                             uint32_t k, uint32_t probes_per_level, uint32_t rerank_factor,
+                                             uint32_t flags, uint64_t *out_ids, float *out_dist, uint32_t *out_count,
+                                             cuddle_stats *stats) {
+    if (!idx) return fail(CUDDLE_ERR_BAD_ARG, "index is null");
+    if (!queries || !out_ids || !out_dist) return fail(CUDDLE_ERR_BAD_ARG, "null query or output pointer");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    if (dim != idx->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, idx->dev.dim);
+    if (k == 0) return fail(CUDDLE_ERR_BAD_ARG, "k must be >= 1 (the reference underflows k-1, hierarchical.rs:651)");
+    HostIO io;
+    ST_TRY(carve_io(idx, std::max(n_queries, 1u), dim, k, 0, io, nullptr));
+    if (n_queries) HIP_TRY(hipMemcpy(io.q, queries, (size_t)n_queries * dim * 4, hipMemcpyHostToDevice));
+    ST_TRY(search_device_locked(idx, io.q, n_queries, dim, k, probes_per_level, rerank_factor, flags, io.ids, io.dist,
+                                io.count, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    if (n_queries) {
+        HIP_TRY(hipMemcpy(out_ids, io.ids, (size_t)n_queries * k * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_dist, io.dist, (size_t)n_queries * k * 4, hipMemcpyDeviceToHost));
+        if (out_count) HIP_TRY(hipMemcpy(out_count, io.count, (size_t)n_queries * 4, hipMemcpyDeviceToHost));
+    }
+    if (stats) ST_TRY(read_stats(idx, stats));
+    return CUDDLE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage entry points
+// ---------------------------------------------------------------------------------------------
+struct TmpDev { // scope-bound device allocation for the pair kernels
+    void *p = nullptr;
+    ~TmpDev() { if (p) (void)hipFree(p); }
+    cuddle_status alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) { p = nullptr; return fail(CUDDLE_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        return CUDDLE_OK;
+    }
+};
+
+extern "C" cuddle_status cuddle_distance_pairs(const float *a, const float *b, uint64_t n, uint32_t dim, uint32_t metric,
+                                               float *out, int device_id) {
+    if ((!a || !b || !out) && n) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    if (metric > CUDDLE_METRIC_DOT) return fail(CUDDLE_ERR_BAD_ARG, "unknown metric %u", metric);
+    ST_TRY(use_device(device_id));
+    if (n == 0) return CUDDLE_OK;
+    TmpDev da, db, dout;
+    size_t bytes = (size_t)n * dim * 4;
+    ST_TRY(da.alloc(bytes)); ST_TRY(db.alloc(bytes)); ST_TRY(dout.alloc(n * 4));
+    if (bytes) {
+        HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    }
+    uint64_t threads = n * 4;
+    hipLaunchKernelGGL(distance_pairs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, (const float *)da.p,
+                       (const float *)db.p, n, dim, metric, (float *)dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_binary_quantize(const float *vectors, uint64_t n, uint32_t dim, float threshold,
+                                                uint64_t *codes, int device_id) {
+    if ((!vectors || !codes) && n) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    if (dim == 0) return fail(CUDDLE_ERR_BAD_ARG, "dim must be >= 1");
+    ST_TRY(use_device(device_id));
+    if (n == 0) return CUDDLE_OK;
+    const uint32_t W = (dim + 63) / 64;
+    TmpDev dv, dc;
+    ST_TRY(dv.alloc((size_t)n * dim * 4)); ST_TRY(dc.alloc((size_t)n * W * 8));
+    HIP_TRY(hipMemcpy(dv.p, vectors, (size_t)n * dim * 4, hipMemcpyHostToDevice));
+    uint64_t total = n * W;
+    hipLaunchKernelGGL(binary_quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, (const float *)dv.p, n,
+                       dim, W, threshold, (uint64_t *)dc.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(codes, dc.p, (size_t)n * W * 8, hipMemcpyDeviceToHost));
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_hamming_pairs(const uint64_t *a, const uint64_t *b, uint64_t n, uint32_t words,
+                                              uint32_t *out, int device_id) {
+    if ((!a || !b || !out) && n) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    ST_TRY(use_device(device_id));
+    if (n == 0) return CUDDLE_OK;
+    TmpDev da, db, dout;
+    size_t bytes = (size_t)n * words * 8;
+    ST_TRY(da.alloc(bytes)); ST_TRY(db.alloc(bytes)); ST_TRY(dout.alloc(n * 4));
+    if (bytes) {
+        HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(hamming_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const uint64_t *)da.p,
+                       (const uint64_t *)db.p, n, words, (uint32_t *)dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
+    return CUDDLE_OK;
+}
+
+// BinaryQuantizer::from_vectors (binary.rs:122-141): sequential f32 fold, then / (count as f32).
+extern "C" float cuddle_binary_threshold(const float *vectors, uint64_t n, uint32_t dim) {
+    volatile float total = 0.0f; // volatile: keep the strictly sequential single-precision fold
+    const uint64_t count = n * (uint64_t)dim;
+    float t = 0.0f;
+    for (uint64_t i = 0; i < count; ++i) t += vectors[i];
+    total = t;
+    return total / (float)count;
+}
+
+extern "C" cuddle_status cuddle_route_batch(cuddle_index *idx, const float *queries, uint32_t n_queries, uint32_t dim,
+                                            uint32_t probes_per_level, uint32_t flags, uint32_t *out_leaves,
+                                            uint32_t leaf_stride, uint32_t *out_leaf_count) {
+    if (!idx) return fail(CUDDLE_ERR_BAD_ARG, "index is null");
+    if (!queries || !out_leaves || !out_leaf_count) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    if (dim != idx->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, idx->dev.dim);
+    if (probes_per_level == 0) return fail(CUDDLE_ERR_BAD_ARG, "probes_per_level must be >= 1");
+    if (n_queries == 0) return CUDDLE_OK;
+    Plan pl;
+    ST_TRY(make_plan(idx, n_queries, 1, probes_per_level, 1, 0, pl));
+    HostIO io;
+    ST_TRY(carve_io(idx, pl.qc, dim, 1, 0, io, nullptr));
+    idx->timed = false;
+    for (uint32_t q0 = 0; q0 < n_queries; q0 += pl.qc) {
+        const uint32_t qc = std::min(pl.qc, n_queries - q0);
+        HIP_TRY(hipMemcpy(io.q, queries + (uint64_t)q0 * dim, (size_t)qc * dim * 4, hipMemcpyHostToDevice));
+        ST_TRY(launch_route(idx, pl, io.q, qc, flags, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        HIP_TRY(hipMemcpy(out_leaf_count + q0, pl.lcount, (size_t)qc * 4, hipMemcpyDeviceToHost));
+        for (uint32_t q = 0; q < qc; ++q)
+            if (out_leaf_count[q0 + q] > leaf_stride)
+                return fail(CUDDLE_ERR_BAD_ARG, "leaf_stride %u too small (query %u reaches %u leaves)", leaf_stride, q0 + q,
+                            out_leaf_count[q0 + q]);
+        const size_t w = (size_t)std::min(pl.lstride, leaf_stride) * 4;
+        HIP_TRY(hipMemcpy2D(out_leaves + (uint64_t)q0 * leaf_stride, (size_t)leaf_stride * 4, pl.leaves, (size_t)pl.lstride * 4, w,
+                            qc, hipMemcpyDeviceToHost));
+    }
+    return CUDDLE_OK;
+}
+
+// Uploads caller-given leaf lists of one chunk into the plan's leaf buffers.
+static cuddle_status upload_leaves(cuddle_index *ix, const Plan &pl, const uint32_t *leaves, uint32_t leaf_stride,
+                                   const uint32_t *leaf_count, uint32_t q0, uint32_t qc) {
+    for (uint32_t q = 0; q < qc; ++q) {
+        if (leaf_count[q0 + q] > leaf_stride) return fail(CUDDLE_ERR_BAD_ARG, "leaf_count[%u] > leaf_stride", q0 + q);
+        for (uint32_t i = 0; i < leaf_count[q0 + q]; ++i)
+            if (leaves[(uint64_t)(q0 + q) * leaf_stride + i] >= ix->dev.n_nodes)
+                return fail(CUDDLE_ERR_BAD_ARG, "leaf id out of range (query %u)", q0 + q);
+    }
+    const size_t w = (size_t)std::min(pl.lstride, leaf_stride) * 4;
+    HIP_TRY(hipMemcpy2D(pl.leaves, (size_t)pl.lstride * 4, leaves + (uint64_t)q0 * leaf_stride, (size_t)leaf_stride * 4, w, qc,
+                        hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pl.lcount, leaf_count + q0, (size_t)qc * 4, hipMemcpyHostToDevice));
+    return CUDDLE_OK;
+}
+
+static uint32_t max_u32(const uint32_t *v, uint32_t n) {
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; ++i) m = std::max(m, v[i]);
+    return m;
+}
+
+extern "C" cuddle_status cuddle_scan_batch(cuddle_index *idx, const float *queries, uint32_t n_queries, uint32_t dim,
+                                           const uint32_t *leaves, uint32_t leaf_stride, const uint32_t *leaf_count,
+                                           uint64_t *out_pos, uint32_t *out_key, uint32_t cand_stride,
+                                           uint32_t *out_cand_count) {
+    if (!idx) return fail(CUDDLE_ERR_BAD_ARG, "index is null");
+    if (!queries || !leaves || !leaf_count || !out_pos || !out_key || !out_cand_count) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    if (dim != idx->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, idx->dev.dim);
+    if (n_queries == 0) return CUDDLE_OK;
+    if (idx->dev.code_kind != CUDDLE_CODE_BINARY) return fail(CUDDLE_ERR_UNSUPPORTED, "RaBitQ scan is not built yet");
+    Plan pl;
+    ST_TRY(make_plan(idx, n_queries, 1, 1, 1, max_u32(leaf_count, n_queries), pl));
+    HostIO io;
+    char *extra = nullptr;
+    const size_t per_q = (size_t)cand_stride * 12;
+    ST_TRY(carve_io(idx, pl.qc, dim, 1, (size_t)pl.qc * per_q + 512, io, &extra));
+    uint64_t *d_pos = (uint64_t *)extra;
+    uint32_t *d_key = (uint32_t *)(extra + align_up((size_t)pl.qc * cand_stride * 8, 256));
+    idx->timed = false;
+    for (uint32_t q0 = 0; q0 < n_queries; q0 += pl.qc) {
+        const uint32_t qc = std::min(pl.qc, n_queries - q0);
+        HIP_TRY(hipMemcpy(io.q, queries + (uint64_t)q0 * dim, (size_t)qc * dim * 4, hipMemcpyHostToDevice));
+        ST_TRY(upload_leaves(idx, pl, leaves, leaf_stride, leaf_count, q0, qc));
+        ST_TRY(launch_quantize(idx, pl, io.q, qc, nullptr));
+        size_t lds = scan_lds_bytes(idx->dev.dim, idx->dev.words, pl.lstride, 0);
+        hipLaunchKernelGGL(scan_all_hamming_kernel, dim3(qc), dim3(256), lds, nullptr, idx->dev, pl.qcodes, pl.leaves,
+                           pl.lstride, pl.lcount, pl.lstride, d_pos, d_key, cand_stride, pl.cand_count);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        HIP_TRY(hipMemcpy(out_cand_count + q0, pl.cand_count, (size_t)qc * 4, hipMemcpyDeviceToHost));
+        for (uint32_t q = 0; q < qc; ++q)
+            if (out_cand_count[q0 + q] > cand_stride)
+                return fail(CUDDLE_ERR_BAD_ARG, "cand_stride %u too small (query %u has %u candidates)", cand_stride, q0 + q,
+                            out_cand_count[q0 + q]);
+        HIP_TRY(hipMemcpy(out_pos + (uint64_t)q0 * cand_stride, d_pos, (size_t)qc * cand_stride * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_key + (uint64_t)q0 * cand_stride, d_key, (size_t)qc * cand_stride * 4, hipMemcpyDeviceToHost));
+    }
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_search_leaves_batch(cuddle_index *idx, const float *queries, uint32_t n_queries,
+                                                    uint32_t dim, const uint32_t *leaves, uint32_t leaf_stride,
+                                                    const uint32_t *leaf_count, uint32_t k, uint32_t rerank_factor,
+                                                    uint32_t flags, uint64_t *out_ids, float *out_dist,
+                                                    uint32_t *out_count, uint64_t *sel_pos, uint32_t *sel_key,
+                                                    float *sel_dist, uint32_t sel_stride, uint32_t *sel_count) {
+    if (!idx) return fail(CUDDLE_ERR_BAD_ARG, "index is null");
+    if (!queries || !leaves || !leaf_count || !out_ids || !out_dist) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    if (dim != idx->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, idx->dev.dim);
+    uint64_t rerank_k;
+    ST_TRY(rerank_k_of(k, rerank_factor, flags, rerank_k));
+    if (n_queries == 0) return CUDDLE_OK;
+    Plan pl;
+    ST_TRY(make_plan(idx, n_queries, k, 1, rerank_k, max_u32(leaf_count, n_queries), pl));
+    const bool want_sel = sel_pos && sel_key && sel_count;
+    HostIO io;
+    char *extra = nullptr;
+    const size_t sel_bytes = want_sel ? (size_t)pl.qc * sel_stride * 16 + 1024 : 0;
+    ST_TRY(carve_io(idx, pl.qc, dim, k, sel_bytes, io, &extra));
+    uint64_t *d_spos = (uint64_t *)extra;
+    uint32_t *d_skey = want_sel ? (uint32_t *)(extra + align_up((size_t)pl.qc * sel_stride * 8, 256)) : nullptr;
+    float *d_sdist = want_sel ? (float *)((char *)d_skey + align_up((size_t)pl.qc * sel_stride * 4, 256)) : nullptr;
+    idx->timed = false;
+    for (uint32_t q0 = 0; q0 < n_queries; q0 += pl.qc) {
+        const uint32_t qc = std::min(pl.qc, n_queries - q0);
+        HIP_TRY(hipMemcpy(io.q, queries + (uint64_t)q0 * dim, (size_t)qc * dim * 4, hipMemcpyHostToDevice));
+        ST_TRY(upload_leaves(idx, pl, leaves, leaf_stride, leaf_count, q0, qc));
+        ST_TRY(launch_quantize(idx, pl, io.q, qc, nullptr));
+        ST_TRY(launch_scan_select(idx, pl, qc, nullptr));
+        ST_TRY(launch_rerank(idx, pl, io.q, qc, nullptr));
+        ST_TRY(launch_topk(idx, pl, qc, io.ids, io.dist, io.count, nullptr));
+        if (want_sel) {
+            size_t lds = (size_t)host_next_pow2(pl.sstride) * 8;
+            hipLaunchKernelGGL(selection_order_kernel, dim3(qc), dim3(256), lds, nullptr, pl.sel_pos, pl.sel_key, pl.sel_dist,
+                               pl.sstride, pl.sel_count, idx->dev.code_kind == CUDDLE_CODE_RABITQ ? 1u : 0u, d_spos, d_skey,
+                               d_sdist, sel_stride);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        HIP_TRY(hipMemcpy(out_ids + (uint64_t)q0 * k, io.ids, (size_t)qc * k * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_dist + (uint64_t)q0 * k, io.dist, (size_t)qc * k * 4, hipMemcpyDeviceToHost));
+        if (out_count) HIP_TRY(hipMemcpy(out_count + q0, io.count, (size_t)qc * 4, hipMemcpyDeviceToHost));
+        if (want_sel) {
+            HIP_TRY(hipMemcpy(sel_count + q0, pl.sel_count, (size_t)qc * 4, hipMemcpyDeviceToHost));
+            for (uint32_t q = 0; q < qc; ++q)
+                if (sel_count[q0 + q] > sel_stride) return fail(CUDDLE_ERR_BAD_ARG, "sel_stride %u too small", sel_stride);
+            HIP_TRY(hipMemcpy(sel_pos + (uint64_t)q0 * sel_stride, d_spos, (size_t)qc * sel_stride * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(sel_key + (uint64_t)q0 * sel_stride, d_skey, (size_t)qc * sel_stride * 4, hipMemcpyDeviceToHost));
+            if (sel_dist)
+                HIP_TRY(hipMemcpy(sel_dist + (uint64_t)q0 * sel_stride, d_sdist, (size_t)qc * sel_stride * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    return CUDDLE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU merge (host)
+// ---------------------------------------------------------------------------------------------
+extern "C" cuddle_status cuddle_merge_topk(const uint64_t *lists_ids, const float *lists_dist, uint32_t n_lists,
+                                           uint32_t n_queries, uint32_t k, uint64_t *out_ids, float *out_dist,
+                                           uint32_t *out_count) {
+    if (!lists_ids || !lists_dist || !out_ids || !out_dist) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    if (k == 0 || n_lists == 0) return fail(CUDDLE_ERR_BAD_ARG, "k and n_lists must be >= 1");
+    struct Item { float d; uint32_t list, rank; uint64_t id; };
+    std::vector<Item> items;
+    items.reserve((size_t)n_lists * k);
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        items.clear();
+        for (uint32_t l = 0; l < n_lists; ++l)
+            for (uint32_t r = 0; r < k; ++r) {
+                size_t o = ((size_t)l * n_queries + q) * k + r;
+                if (lists_ids[o] == UINT64_MAX) break;
+                items.push_back({lists_dist[o], l, r, lists_ids[o]});
+            }
+        std::sort(items.begin(), items.end(), [](const Item &a, const Item &b) {
+            if (a.d < b.d) return true;
+            if (a.d > b.d) return false;
+            if (a.list != b.list) return a.list < b.list;
+            return a.rank < b.rank;
+        });
+        uint32_t n = (uint32_t)std::min<size_t>(items.size(), k);
+        for (uint32_t i = 0; i < k; ++i) {
+            out_ids[(size_t)q * k + i] = i < n ? items[i].id : UINT64_MAX;
+            out_dist[(size_t)q * k + i] = i < n ? items[i].d : std::numeric_limits<float>::infinity();
+        }
+        if (out_count) out_count[q] = n;
+    }
+    return CUDDLE_OK;
+}

@@ -1,0 +1,845 @@
+// cuddle_kernels.hpp — device code of libcuddle_hip (gfx950 / CDNA4, wave64).
+//
+// Kernels of the batched two-phase query path. Every arithmetic routine states which
+// reference routine it reproduces; floating-point results are bit-identical to that routine's
+// accumulation order (fused multiply-add exactly where the reference uses vfmaq_f32), so the
+// translation unit must be compiled with -ffp-contract=off.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cuddle {
+
+constexpr int kWave = 64;
+constexpr uint32_t kMetricL2 = 0, kMetricCosine = 1, kMetricDot = 2;
+constexpr uint32_t kSortCap = 4096;      // max probes_per_level (sorted selection lives in LDS)
+constexpr uint32_t kMaxRerankK = 16384;  // max phase-1 selection per query (final sort lives in LDS)
+
+// Device view of an index (all pointers are device pointers).
+struct IndexDev {
+    uint32_t dim;
+    uint32_t words;        // u64 words per binary code = ceil(dim/64)
+    uint32_t metric;
+    uint32_t code_kind;
+    uint32_t n_nodes;
+    uint32_t n_roots;
+    uint64_t n_vectors;
+    const float *centroids;       // [n_nodes][dim]
+    const float *centroid_sqnorm; // [n_nodes]  fma-chain sum of squares (MFMA routing)
+    const uint32_t *child_off;    // [n_nodes+1]
+    const uint32_t *children;
+    const uint32_t *roots;
+    const uint32_t *vec_off;      // [n_nodes+1] leaf-contiguous positions
+    const uint32_t *code_off;     // [n_nodes]   start of the leaf's planar code block, 16-byte units
+    const uint64_t *ids;          // [n_vectors]
+    const float *vectors;         // [n_vectors][dim]
+    const uint4 *codes;           // planar per-leaf binary codes (see relayout_codes_kernel)
+    // RaBitQ
+    const float *rot_t;           // [dim][dim]
+    const uint32_t *rq_codes;     // planar per-leaf: word-major [words32][n] per leaf
+    const float *rq_norm;         // [n_vectors]
+    const float *rq_ipoo;         // [n_vectors]
+    uint32_t words32;             // ceil(dim/32)
+};
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+
+// Order-preserving map f32 -> u32 for "a < b" comparisons as the reference's partial_cmp sees
+// them: -0.0 == +0.0, NaN after everything.
+__device__ __forceinline__ uint32_t f32_key(float d) {
+    if (d != d) return 0xFFFFFFFFu;
+    uint32_t b = __float_as_uint(d);
+    if ((b << 1) == 0u) b = 0u;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+// Inclusive prefix sum across the 64 lanes of a wave.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if ((int)(threadIdx.x & 63) >= o) v += t;
+    }
+    return v;
+}
+
+// In-place exclusive prefix sum of lds[0..n) by the first wave of the block; lds[n] receives
+// the total. Callers barrier before and after.
+__device__ __forceinline__ void wave0_exclusive_scan_lds(uint32_t *lds, uint32_t n) {
+    if (threadIdx.x >= 64) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t per = (n + 63) / 64;
+    const uint32_t b = lane * per;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < per; ++i)
+        if (b + i < n) sum += lds[b + i];
+    uint32_t incl = wave_inclusive_sum(sum);
+    uint32_t run = incl - sum;
+    for (uint32_t i = 0; i < per; ++i)
+        if (b + i < n) {
+            uint32_t v = lds[b + i];
+            lds[b + i] = run;
+            run += v;
+        }
+    if (lane == 63) lds[n] = incl;
+}
+
+// Bitonic sort of n (power of two) u64 keys in LDS, ascending. All threads of the block call.
+__device__ __forceinline__ void block_bitonic_sort_u64(uint64_t *s, uint32_t n) {
+    for (uint32_t k = 2; k <= n; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+                uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    uint64_t a = s[i], b = s[ixj];
+                    bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        s[i] = b;
+                        s[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t next_pow2(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// Ordered threshold compaction. Over items i in [0, C) with integer keys key(i), emit every item
+// with key < T and the first `budget` items (in index order) with key == T, calling
+// emit(i, key, rank) with rank = the item's position among the emitted ones in index order.
+// Each wave owns one contiguous segment; wtmp needs 2 * (blockDim.x / 64) u32 of LDS.
+// All threads of the block call; contains two barriers.
+template <class KeyFn, class EmitFn>
+__device__ __forceinline__ void ordered_threshold_compact(uint32_t C, uint32_t T, uint32_t budget,
+                                                          KeyFn key, EmitFn emit, uint32_t *wtmp) {
+    const uint32_t nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t seg = (C + nw - 1) / nw;
+    seg = (seg + 63) & ~63u;
+    const uint32_t beg = min(w * seg, C), end = min(beg + seg, C);
+    uint32_t n_lt = 0, n_tie = 0;
+    for (uint32_t i0 = beg; i0 < end; i0 += 64) {
+        uint32_t i = i0 + lane;
+        uint32_t kv = (i < end) ? key(i) : 0xFFFFFFFFu;
+        n_lt += __popcll(__ballot(i < end && kv < T));
+        n_tie += __popcll(__ballot(i < end && kv == T));
+    }
+    if (lane == 0) {
+        wtmp[w] = n_lt;
+        wtmp[nw + w] = n_tie;
+    }
+    __syncthreads();
+    uint32_t lt_before = 0, tie_before = 0;
+    for (uint32_t v = 0; v < w; ++v) {
+        lt_before += wtmp[v];
+        tie_before += wtmp[nw + v];
+    }
+    uint32_t out_before = lt_before + min(tie_before, budget);
+    const uint64_t lm = lanemask_lt();
+    for (uint32_t i0 = beg; i0 < end; i0 += 64) {
+        uint32_t i = i0 + lane;
+        bool in = i < end;
+        uint32_t kv = in ? key(i) : 0xFFFFFFFFu;
+        bool tie = in && kv == T;
+        uint64_t tb = __ballot(tie);
+        uint32_t tie_rank = tie_before + __popcll(tb & lm);
+        bool flag = in && (kv < T || (tie && tie_rank < budget));
+        uint64_t fb = __ballot(flag);
+        if (flag) emit(i, kv, out_before + (uint32_t)__popcll(fb & lm));
+        tie_before += __popcll(tb);
+        out_before += __popcll(fb);
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact distances in the reference's accumulation order
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float4 ld4(const float *p, bool vec) {
+    if (vec) return *reinterpret_cast<const float4 *>(p);
+    return make_float4(p[0], p[1], p[2], p[3]);
+}
+
+// Tails shared by the dot / L2 routines after the 16-wide main loop
+// (simd_neon.rs:54-67 and :122-137): 4-element chunks with a separately rounded multiply and a
+// pairwise add, then single elements.
+template <bool L2>
+__device__ __forceinline__ float neon_tail(float r, const float *a, const float *b, uint32_t i, uint32_t n) {
+    for (; i + 4 <= n; i += 4) {
+        float x0, x1, x2, x3;
+        if (L2) {
+            float d0 = a[i] - b[i], d1 = a[i + 1] - b[i + 1], d2 = a[i + 2] - b[i + 2], d3 = a[i + 3] - b[i + 3];
+            x0 = d0 * d0; x1 = d1 * d1; x2 = d2 * d2; x3 = d3 * d3;
+        } else {
+            x0 = a[i] * b[i]; x1 = a[i + 1] * b[i + 1]; x2 = a[i + 2] * b[i + 2]; x3 = a[i + 3] * b[i + 3];
+        }
+        r += (x0 + x1) + (x2 + x3);
+    }
+    for (; i < n; ++i) {
+        if (L2) {
+            float d = a[i] - b[i];
+            r += d * d;
+        } else {
+            r += a[i] * b[i];
+        }
+    }
+    return r;
+}
+
+// dot_product_neon / l2_squared_neon (simd_neon.rs:13-70 / :77-140) computed by a group of four
+// consecutive lanes: lane `sub` (0..3) owns the reference's NEON accumulator sum<sub> (four f32
+// lanes, elements 16t+4sub..+3), runs the same fused-multiply-add chain over t, and the four
+// accumulators are combined (sum0+sum1)+(sum2+sum3) lane-wise, then (u0+u1)+(u2+u3) — the
+// vaddvq_f32 pairwise order. All four lanes return the result. a may point to LDS.
+template <bool L2>
+__device__ __forceinline__ float neon16_group4(const float *a, const float *b, uint32_t n, uint32_t sub, bool vec) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t nblk = n >> 4;
+    const float *pa = a + 4 * sub, *pb = b + 4 * sub;
+#pragma unroll 4
+    for (uint32_t t = 0; t < nblk; ++t) {
+        float4 x = ld4(pa + 16 * t, vec), y = ld4(pb + 16 * t, vec);
+        if (L2) {
+            float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+            acc.x = __builtin_fmaf(d0, d0, acc.x);
+            acc.y = __builtin_fmaf(d1, d1, acc.y);
+            acc.z = __builtin_fmaf(d2, d2, acc.z);
+            acc.w = __builtin_fmaf(d3, d3, acc.w);
+        } else {
+            acc.x = __builtin_fmaf(x.x, y.x, acc.x);
+            acc.y = __builtin_fmaf(x.y, y.y, acc.y);
+            acc.z = __builtin_fmaf(x.z, y.z, acc.z);
+            acc.w = __builtin_fmaf(x.w, y.w, acc.w);
+        }
+    }
+    acc.x += __shfl_xor(acc.x, 1, 64); acc.y += __shfl_xor(acc.y, 1, 64);
+    acc.z += __shfl_xor(acc.z, 1, 64); acc.w += __shfl_xor(acc.w, 1, 64);
+    acc.x += __shfl_xor(acc.x, 2, 64); acc.y += __shfl_xor(acc.y, 2, 64);
+    acc.z += __shfl_xor(acc.z, 2, 64); acc.w += __shfl_xor(acc.w, 2, 64);
+    float r = (acc.x + acc.y) + (acc.z + acc.w);
+    return neon_tail<L2>(r, a, b, nblk << 4, n);
+}
+
+// The same routines computed by one lane (16 running partial sums).
+template <bool L2>
+__device__ __forceinline__ float neon16_serial(const float *a, const float *b, uint32_t n) {
+    float s[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s[j] = 0.f;
+    const uint32_t nblk = n >> 4;
+    for (uint32_t t = 0; t < nblk; ++t) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float x = a[16 * t + j], y = b[16 * t + j];
+            if (L2) {
+                float d = x - y;
+                s[j] = __builtin_fmaf(d, d, s[j]);
+            } else {
+                s[j] = __builtin_fmaf(x, y, s[j]);
+            }
+        }
+    }
+    float u[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) u[l] = (s[l] + s[4 + l]) + (s[8 + l] + s[12 + l]);
+    float r = (u[0] + u[1]) + (u[2] + u[3]);
+    return neon_tail<L2>(r, a, b, nblk << 4, n);
+}
+
+// One target of l2_squared_batch4_neon (simd_neon.rs:160-227): a single 4-lane accumulator over
+// elements i = l (mod 4), vaddvq, then a scalar tail.
+__device__ __forceinline__ float l2_batch4_serial(const float *q, const float *t, uint32_t n) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    uint32_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        float d0 = q[i] - t[i], d1 = q[i + 1] - t[i + 1], d2 = q[i + 2] - t[i + 2], d3 = q[i + 3] - t[i + 3];
+        a0 = __builtin_fmaf(d0, d0, a0);
+        a1 = __builtin_fmaf(d1, d1, a1);
+        a2 = __builtin_fmaf(d2, d2, a2);
+        a3 = __builtin_fmaf(d3, d3, a3);
+    }
+    float r = (a0 + a1) + (a2 + a3);
+    for (; i < n; ++i) {
+        float d = q[i] - t[i];
+        r += d * d;
+    }
+    return r;
+}
+
+// distance() (src/distance/mod.rs:23-34) by a 4-lane group. a = query side, b = stored side.
+__device__ __forceinline__ float distance_group4(const float *a, const float *b, uint32_t n, uint32_t metric,
+                                                 uint32_t sub, bool vec) {
+    if (metric == kMetricL2) return neon16_group4<true>(a, b, n, sub, vec);
+    float dot = neon16_group4<false>(a, b, n, sub, vec);
+    if (metric == kMetricDot) return -dot;
+    float na = sqrtf(neon16_group4<false>(a, a, n, sub, vec));
+    float nb = sqrtf(neon16_group4<false>(b, b, n, sub, vec));
+    return 1.0f - (dot / (na * nb));
+}
+
+__device__ __forceinline__ float distance_serial(const float *a, const float *b, uint32_t n, uint32_t metric) {
+    if (metric == kMetricL2) return neon16_serial<true>(a, b, n);
+    float dot = neon16_serial<false>(a, b, n);
+    if (metric == kMetricDot) return -dot;
+    float na = sqrtf(neon16_serial<false>(a, a, n));
+    float nb = sqrtf(neon16_serial<false>(b, b, n));
+    return 1.0f - (dot / (na * nb));
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone pair kernels (stage entry points)
+// ---------------------------------------------------------------------------------------------
+
+// distance() for n independent pairs; one 4-lane group per pair.
+__global__ void distance_pairs_kernel(const float *a, const float *b, uint64_t n, uint32_t dim, uint32_t metric,
+                                      float *out) {
+    uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    uint32_t sub = threadIdx.x & 3;
+    bool act = g < n;
+    uint64_t gg = act ? g : 0; // inactive groups still run the shuffles on pair 0
+    bool vec = (dim & 3) == 0;
+    float d = distance_group4(a + gg * dim, b + gg * dim, dim, metric, sub, vec);
+    if (act && sub == 0) out[g] = d;
+}
+
+// BinaryQuantizer::quantize (binary.rs:144-159): one thread per (vector, word).
+__global__ void binary_quantize_kernel(const float *v, uint64_t n, uint32_t dim, uint32_t words, float thr,
+                                       uint64_t *codes) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * words) return;
+    uint64_t r = t / words;
+    uint32_t w = (uint32_t)(t % words);
+    const float *x = v + r * dim;
+    uint64_t bits = 0;
+    uint32_t lim = min(64u, dim - w * 64u);
+    for (uint32_t i = 0; i < lim; ++i)
+        if (x[w * 64 + i] > thr) bits |= 1ull << i;
+    codes[t] = bits;
+}
+
+// hamming_distance (binary.rs:42-54) for n pairs.
+__global__ void hamming_pairs_kernel(const uint64_t *a, const uint64_t *b, uint64_t n, uint32_t words, uint32_t *out) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    uint32_t d = 0;
+    for (uint32_t w = 0; w < words; ++w) d += __popcll(a[t * words + w] ^ b[t * words + w]);
+    out[t] = d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// index set-up kernels
+// ---------------------------------------------------------------------------------------------
+
+// Re-lay vector-major binary codes [n_vectors][words] into the per-leaf planar layout the scan
+// streams: for a leaf with n vectors starting at 16-byte unit code_off, plane p (p < words/2)
+// holds words (2p, 2p+1) of vector i at 16-byte slot p*n + i; when `words` is odd a last plane of
+// 8-byte entries holds word words-1 of vector i. A wave reading one plane for 64 consecutive
+// vectors issues one fully coalesced 1 KiB load. One thread per (leaf-contiguous position).
+__global__ void relayout_codes_kernel(const uint64_t *src, uint64_t *dst, const uint32_t *vec_off,
+                                      const uint32_t *code_off, const uint32_t *pos_leaf, uint64_t n_vectors,
+                                      uint32_t words) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_vectors) return;
+    uint32_t leaf = pos_leaf[p];
+    uint32_t i = (uint32_t)(p - vec_off[leaf]);
+    uint32_t n = vec_off[leaf + 1] - vec_off[leaf];
+    uint64_t *base = dst + (uint64_t)code_off[leaf] * 2;
+    const uint64_t *s = src + p * words;
+    uint32_t pairs = words >> 1;
+    for (uint32_t q = 0; q < pairs; ++q) {
+        base[((uint64_t)q * n + i) * 2] = s[2 * q];
+        base[((uint64_t)q * n + i) * 2 + 1] = s[2 * q + 1];
+    }
+    if (words & 1) base[(uint64_t)pairs * n * 2 + i] = s[words - 1];
+}
+
+// RaBitQ codes: vector-major [n_vectors][words32] u32 -> per leaf word-major [words32][n].
+__global__ void relayout_rabitq_kernel(const uint32_t *src, uint32_t *dst, const uint32_t *vec_off,
+                                       const uint32_t *pos_leaf, uint64_t n_vectors, uint32_t words32) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_vectors) return;
+    uint32_t leaf = pos_leaf[p];
+    uint64_t beg = vec_off[leaf];
+    uint32_t i = (uint32_t)(p - beg);
+    uint32_t n = vec_off[leaf + 1] - vec_off[leaf];
+    uint32_t *base = dst + beg * words32;
+    for (uint32_t w = 0; w < words32; ++w) base[(uint64_t)w * n + i] = src[p * words32 + w];
+}
+
+// ---------------------------------------------------------------------------------------------
+// routing (hierarchical.rs:349-423)
+// ---------------------------------------------------------------------------------------------
+
+// Level start: frontier = root_ids for every query (hierarchical.rs:346).
+__global__ void route_init_kernel(const uint32_t *roots, uint32_t n_roots, uint32_t *frontier, uint32_t fstride,
+                                  uint32_t *fcount, uint32_t *lcount, uint32_t nq) {
+    uint32_t q = blockIdx.y;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    if (i < n_roots) frontier[(uint64_t)q * fstride + i] = roots[i];
+    if (i == 0) {
+        fcount[q] = n_roots;
+        lcount[q] = 0;
+    }
+}
+
+// Exact distances query -> frontier centroids, in the arithmetic search() uses for that
+// frontier size (hierarchical.rs:355-391): n > 100 or n < 4: distance(metric) per node;
+// 4 <= n <= 100: l2_squared_batch, i.e. batch4 arithmetic for the first 4*floor(n/4) nodes and
+// l2_squared for the rest, whatever the metric. stats_variant: always distance(metric) (:868-886).
+// grid = (ceil(fstride/64), nq), block = 256: one 4-lane group per (query, node).
+__global__ void __launch_bounds__(256)
+route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, uint32_t fstride,
+                  const uint32_t *fcount, float *fdist, uint32_t stats_variant) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *qs = reinterpret_cast<float *>(smem);
+    const uint32_t q = blockIdx.y;
+    const uint32_t n = fcount[q];
+    const uint32_t D = ix.dim;
+    const bool small = !stats_variant && n >= 4 && n <= 100;
+    if (small ? (blockIdx.x != 0) : (blockIdx.x * 64 >= n)) return;
+    const float *qg = queries + (uint64_t)q * D;
+    for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) qs[i] = qg[i];
+    __syncthreads();
+    const uint32_t *fr = frontier + (uint64_t)q * fstride;
+    float *fd = fdist + (uint64_t)q * fstride;
+    if (small) {
+        uint32_t j = threadIdx.x;
+        if (j < n) {
+            const float *c = ix.centroids + (uint64_t)fr[j] * D;
+            fd[j] = (j < (n & ~3u)) ? l2_batch4_serial(qs, c, D) : neon16_serial<true>(qs, c, D);
+        }
+        return;
+    }
+    const uint32_t j = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const uint32_t sub = threadIdx.x & 3;
+    const bool act = j < n;
+    const uint32_t node = fr[act ? j : 0];
+    const bool vec = (D & 3) == 0;
+    float d = distance_group4(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, vec);
+    if (act && sub == 0) fd[j] = d;
+}
+
+// Per query: choose the nodes to descend into (hierarchical.rs:393-408), split them into leaves
+// and internal nodes (:411-413), append the leaves (:416) and build the next frontier from the
+// internal nodes' children (:419-422). One block per query.
+//   n <= probes (and not stats_variant): all nodes, frontier order.
+//   otherwise: the min(n, probes) smallest by (distance, frontier position), in that order.
+// scap (a power of two <= kSortCap) bounds the sorted set: min(n, probes) <= scap whenever n > scap
+// is possible. Dynamic LDS: scap u64 keys + 256 u32 histogram + 2 (scap+1) u32 counters + scratch.
+__global__ void __launch_bounds__(256)
+route_select_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, const uint32_t *fcount,
+                    const float *fdist, uint32_t probes, uint32_t stats_variant, uint32_t scap,
+                    uint32_t *next_frontier, uint32_t *next_fcount, uint32_t *leaves, uint32_t lstride,
+                    uint32_t *lcount) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);                 // [scap]
+    uint32_t *hist = reinterpret_cast<uint32_t *>(skeys + scap);         // [256]
+    uint32_t *wtmp = hist + 256;                                         // [2 * waves]
+    uint32_t *misc = wtmp + 32;                                          // [8]
+    uint32_t *cnt_leaf = misc + 8;                                       // [scap + 1]
+    uint32_t *cnt_child = cnt_leaf + scap + 1;                           // [scap + 1]
+    const uint32_t q = blockIdx.x;
+    const uint32_t n = fcount[q];
+    const uint32_t tid = threadIdx.x;
+    if (n == 0) {
+        if (tid == 0) next_fcount[q] = 0;
+        return;
+    }
+    const uint32_t *fr = frontier + (uint64_t)q * fstride;
+    const float *fd = fdist + (uint64_t)q * fstride;
+    uint32_t nsel;
+    const bool keep_all = !stats_variant && n <= probes;
+    if (keep_all) {
+        nsel = n; // n <= this level's bound <= scap
+        for (uint32_t i = tid; i < n; i += blockDim.x) skeys[i] = i;
+        __syncthreads();
+    } else {
+        nsel = min(n, probes);
+        uint32_t npad;
+        if (n <= scap) {
+            npad = next_pow2(n);
+            for (uint32_t i = tid; i < npad; i += blockDim.x)
+                skeys[i] = i < n ? (((uint64_t)f32_key(fd[i]) << 32) | i) : ~0ull;
+            __syncthreads();
+        } else {
+            // radix select of the nsel-th smallest 32-bit key, 8 bits per pass
+            uint32_t prefix = 0, want = nsel; // want-th smallest (1-based) among keys matching prefix
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                for (uint32_t i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+                __syncthreads();
+                const uint32_t himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+                for (uint32_t i = tid; i < n; i += blockDim.x) {
+                    uint32_t kv = f32_key(fd[i]);
+                    if ((kv & himask) == prefix) atomicAdd(&hist[(kv >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t cum = 0, b = 0;
+                    for (; b < 256; ++b) {
+                        if (cum + hist[b] >= want) break;
+                        cum += hist[b];
+                    }
+                    misc[0] = prefix | (b << shift);
+                    misc[1] = want - cum;
+                }
+                __syncthreads();
+                prefix = misc[0];
+                want = misc[1];
+                __syncthreads();
+            }
+            // prefix = threshold key T; `want` of the items with key == T are taken, in index order
+            const uint32_t T = prefix, budget = want;
+            ordered_threshold_compact(
+                n, T, budget, [&](uint32_t i) { return f32_key(fd[i]); },
+                [&](uint32_t i, uint32_t kv, uint32_t rank) { skeys[rank] = ((uint64_t)kv << 32) | i; }, wtmp);
+            npad = next_pow2(nsel);
+            for (uint32_t i = nsel + tid; i < npad; i += blockDim.x) skeys[i] = ~0ull;
+            __syncthreads();
+        }
+        block_bitonic_sort_u64(skeys, npad);
+    }
+    // skeys[0..nsel): low 32 bits = frontier position of the chosen nodes, in order.
+    for (uint32_t i = tid; i < nsel; i += blockDim.x) {
+        uint32_t node = fr[(uint32_t)skeys[i]];
+        uint32_t cc = ix.child_off[node + 1] - ix.child_off[node];
+        cnt_leaf[i] = cc == 0 ? 1u : 0u;
+        cnt_child[i] = cc;
+    }
+    __syncthreads();
+    wave0_exclusive_scan_lds(cnt_leaf, nsel);
+    __syncthreads();
+    wave0_exclusive_scan_lds(cnt_child, nsel);
+    __syncthreads();
+    const uint32_t lbase = lcount[q];
+    uint32_t *lv = leaves + (uint64_t)q * lstride;
+    uint32_t *nf = next_frontier + (uint64_t)q * fstride;
+    // one wave per chosen node: leaves are appended, children copied with coalesced stores
+    const uint32_t nw = blockDim.x >> 6, w = tid >> 6, lane = tid & 63;
+    for (uint32_t i = w; i < nsel; i += nw) {
+        uint32_t node = fr[(uint32_t)skeys[i]];
+        uint32_t cb = ix.child_off[node], ce = ix.child_off[node + 1];
+        if (cb == ce) {
+            if (lane == 0) {
+                uint32_t slot = lbase + cnt_leaf[i];
+                if (slot < lstride) lv[slot] = node;
+            }
+        } else {
+            uint32_t ob = cnt_child[i];
+            for (uint32_t c = lane; c < ce - cb; c += 64)
+                if (ob + c < fstride) nf[ob + c] = ix.children[cb + c];
+        }
+    }
+    if (tid == 0) {
+        lcount[q] = min(lbase + cnt_leaf[nsel], lstride);
+        next_fcount[q] = min(cnt_child[nsel], fstride);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hamming leaf scan + phase-1 selection (hierarchical.rs:591-655)
+// ---------------------------------------------------------------------------------------------
+
+// Hamming distance of vector i of a leaf (n vectors, planar block at `planes`) to the query code
+// qw[0..words) (LDS). 128-bit loads; consecutive lanes read consecutive 16-byte slots.
+__device__ __forceinline__ uint32_t leaf_hamming(const uint4 *planes, uint32_t n, uint32_t i, const uint64_t *qw,
+                                                 uint32_t words) {
+    const uint32_t pairs = words >> 1;
+    uint32_t h = 0;
+    for (uint32_t p = 0; p < pairs; ++p) {
+        uint4 c = planes[(uint64_t)p * n + i];
+        uint64_t a = ((uint64_t)c.y << 32) | c.x, b = ((uint64_t)c.w << 32) | c.z;
+        h += __popcll(a ^ qw[2 * p]) + __popcll(b ^ qw[2 * p + 1]);
+    }
+    if (words & 1) {
+        const uint2 *tail = reinterpret_cast<const uint2 *>(planes + (uint64_t)pairs * n);
+        uint2 c = tail[i];
+        uint64_t a = ((uint64_t)c.y << 32) | c.x;
+        h += __popcll(a ^ qw[words - 1]);
+    }
+    return h;
+}
+
+// LDS carve-up shared by the scan kernels.
+struct ScanLds {
+    uint32_t *hist;     // [dim + 2]
+    uint32_t *lbeg;     // [lcap]      first leaf-contiguous position of each leaf slot
+    uint32_t *lcode;    // [lcap]      16-byte unit offset of the leaf's planar codes
+    uint32_t *lscan;    // [lcap + 1]  exclusive prefix of leaf sizes = scan position of the leaf
+    uint32_t *wtmp;     // [32]
+    uint32_t *misc;     // [8]
+    uint64_t *qw;       // [words]
+    uint16_t *dist;     // [dist_cap]
+};
+
+__device__ __forceinline__ ScanLds scan_lds_carve(unsigned char *smem, uint32_t dim, uint32_t words, uint32_t lcap) {
+    ScanLds s;
+    uint32_t *p = reinterpret_cast<uint32_t *>(smem);
+    s.hist = p; p += ((dim + 2 + 3) & ~3u);
+    s.lbeg = p; p += ((lcap + 3) & ~3u);
+    s.lcode = p; p += ((lcap + 3) & ~3u);
+    s.lscan = p; p += ((lcap + 1 + 3) & ~3u);
+    s.wtmp = p; p += 32;
+    s.misc = p; p += 8;
+    s.qw = reinterpret_cast<uint64_t *>(p); p += 2 * ((words + 1) & ~1u);
+    s.dist = reinterpret_cast<uint16_t *>(p);
+    return s;
+}
+
+inline size_t scan_lds_bytes(uint32_t dim, uint32_t words, uint32_t lcap, uint32_t dist_cap) {
+    size_t u32s = ((dim + 2 + 3) & ~3u) + 2 * (size_t)((lcap + 3) & ~3u) + ((lcap + 1 + 3) & ~3u) + 32 + 8 +
+                  2 * (size_t)((words + 1) & ~1u);
+    return u32s * 4 + (size_t)dist_cap * 2;
+}
+
+// Loads the query's leaf descriptors into LDS and prefix-sums the leaf sizes. Returns the number
+// of candidates C. All threads call.
+__device__ __forceinline__ uint32_t scan_load_leaves(const IndexDev &ix, const ScanLds &s, const uint32_t *lv,
+                                                     uint32_t nl) {
+    for (uint32_t t = threadIdx.x; t < nl; t += blockDim.x) {
+        uint32_t node = lv[t];
+        uint32_t b = ix.vec_off[node], e = ix.vec_off[node + 1];
+        s.lbeg[t] = b;
+        s.lscan[t] = e - b;
+        s.lcode[t] = ix.code_off[node];
+    }
+    __syncthreads();
+    wave0_exclusive_scan_lds(s.lscan, nl);
+    __syncthreads();
+    return s.lscan[nl];
+}
+
+// Leaf slot that contains scan position i (largest s with lscan[s] <= i, skipping empty leaves).
+__device__ __forceinline__ uint32_t scan_slot_of(const uint32_t *lscan, uint32_t nl, uint32_t i) {
+    uint32_t lo = 0, hi = nl; // invariant: lscan[lo] <= i < lscan[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (lscan[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// One block per query. Phase 1 streams the planar codes of every reached leaf (one wave per leaf
+// at a time, lane = vector), XOR + popcount against the query code, and keeps each candidate's
+// Hamming distance as u16 (LDS when the query's candidates fit in dist_cap, else the global
+// spill buffer) while building a (dim+1)-bin histogram. Phase 2 turns the histogram into the
+// selection threshold: T = smallest h with #(<= h) >= rerank_k, budget = rerank_k - #(< T).
+// Phase 3 emits, in scan order, every candidate with h < T and the first `budget` with h == T:
+// the first rerank_k elements of the reference's stable sort_by_key (hierarchical.rs:646-648,
+// :930-932), i.e. a legal result of select_nth_unstable_by (:651), listed in scan order.
+// sel_pos / sel_key: [nq][sel_stride]; gdist: [nq][gdist_stride] u16 spill (may be null when
+// dist_cap always suffices).
+__global__ void __launch_bounds__(512)
+scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *leaves, uint32_t lstride,
+                           const uint32_t *lcount, uint32_t lcap, uint32_t rerank_k, uint32_t dist_cap,
+                           uint16_t *gdist, uint32_t gdist_stride, uint32_t *sel_pos, uint32_t *sel_key,
+                           uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const uint32_t D = ix.dim, W = ix.words;
+    ScanLds s = scan_lds_carve(smem, D, W, lcap);
+    const uint32_t nl = min(lcount[q], lcap);
+    for (uint32_t i = tid; i < D + 2; i += blockDim.x) s.hist[i] = 0;
+    for (uint32_t i = tid; i < W; i += blockDim.x) s.qw[i] = qcodes[(uint64_t)q * W + i];
+    const uint32_t C = scan_load_leaves(ix, s, leaves + (uint64_t)q * lstride, nl);
+    if (tid == 0) cand_count[q] = C;
+    if (C == 0) {
+        if (tid == 0) sel_count[q] = 0;
+        return;
+    }
+    const bool use_lds = C <= dist_cap;
+    uint16_t *gd = gdist + (uint64_t)q * gdist_stride;
+    // phase 1
+    for (uint32_t sl = w; sl < nl; sl += nw) {
+        const uint32_t n = s.lscan[sl + 1] - s.lscan[sl], base = s.lscan[sl];
+        const uint4 *planes = ix.codes + s.lcode[sl];
+        for (uint32_t i = lane; i < n; i += 64) {
+            uint32_t h = leaf_hamming(planes, n, i, s.qw, W);
+            if (use_lds) s.dist[base + i] = (uint16_t)h; else gd[base + i] = (uint16_t)h;
+            atomicAdd(&s.hist[h], 1u);
+        }
+    }
+    __syncthreads();
+    // phase 2
+    uint32_t T, budget;
+    if (C <= rerank_k) {
+        T = D + 1; // every candidate is < T
+        budget = 0;
+    } else {
+        if (w == 0) {
+            uint32_t carry = 0;
+            bool done = false;
+            for (uint32_t b0 = 0; b0 <= D && !done; b0 += 64) {
+                uint32_t b = b0 + lane;
+                uint32_t v = b <= D ? s.hist[b] : 0;
+                uint32_t incl = wave_inclusive_sum(v) + carry;
+                uint64_t hit = __ballot(incl >= rerank_k);
+                if (hit) {
+                    uint32_t first = __ffsll((unsigned long long)hit) - 1;
+                    uint32_t incl_f = __shfl(incl, first, 64), v_f = __shfl(v, first, 64);
+                    if (lane == 0) {
+                        s.misc[0] = b0 + first;
+                        s.misc[1] = rerank_k - (incl_f - v_f);
+                    }
+                    done = true;
+                }
+                carry = __shfl(incl, 63, 64);
+            }
+        }
+        __syncthreads();
+        T = s.misc[0];
+        budget = s.misc[1];
+    }
+    // phase 3
+    uint32_t *sp = sel_pos + (uint64_t)q * sel_stride, *sk = sel_key + (uint64_t)q * sel_stride;
+    ordered_threshold_compact(
+        C, T, budget, [&](uint32_t i) -> uint32_t { return use_lds ? s.dist[i] : gd[i]; },
+        [&](uint32_t i, uint32_t kv, uint32_t rank) {
+            if (rank < sel_stride) {
+                uint32_t sl = scan_slot_of(s.lscan, nl, i);
+                sp[rank] = s.lbeg[sl] + (i - s.lscan[sl]);
+                sk[rank] = kv;
+            }
+        },
+        s.wtmp);
+    if (tid == 0) sel_count[q] = min(min(C, rerank_k), sel_stride);
+}
+
+// collect_leaf_candidates (hierarchical.rs:618-641) written out in full: every candidate's
+// leaf-contiguous position and Hamming distance in scan order. Stage entry point for parity tests.
+__global__ void __launch_bounds__(256)
+scan_all_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *leaves, uint32_t lstride,
+                        const uint32_t *lcount, uint32_t lcap, uint64_t *out_pos, uint32_t *out_key,
+                        uint32_t cand_stride, uint32_t *cand_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const uint32_t W = ix.words;
+    ScanLds s = scan_lds_carve(smem, ix.dim, W, lcap);
+    const uint32_t nl = min(lcount[q], lcap);
+    for (uint32_t i = tid; i < W; i += blockDim.x) s.qw[i] = qcodes[(uint64_t)q * W + i];
+    const uint32_t C = scan_load_leaves(ix, s, leaves + (uint64_t)q * lstride, nl);
+    if (tid == 0) cand_count[q] = C;
+    for (uint32_t sl = w; sl < nl; sl += nw) {
+        const uint32_t n = s.lscan[sl + 1] - s.lscan[sl], base = s.lscan[sl];
+        const uint4 *planes = ix.codes + s.lcode[sl];
+        for (uint32_t i = lane; i < n; i += 64) {
+            uint32_t h = leaf_hamming(planes, n, i, s.qw, W);
+            if (base + i < cand_stride) {
+                out_pos[(uint64_t)q * cand_stride + base + i] = s.lbeg[sl] + i;
+                out_key[(uint64_t)q * cand_stride + base + i] = h;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rerank (hierarchical.rs:659-674) and final top-k (:678-691)
+// ---------------------------------------------------------------------------------------------
+
+// distance(query, full_vectors.get(idx), metric) for every selected candidate. grid =
+// (ceil(sel_stride/64), nq), block 256: the query is staged in LDS once per block, each 4-lane
+// group streams one candidate row with 128-bit loads (64 contiguous bytes per group and step).
+__global__ void __launch_bounds__(256)
+rerank_kernel(IndexDev ix, const float *queries, const uint32_t *sel_pos, uint32_t sel_stride,
+              const uint32_t *sel_count, float *sel_dist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *qs = reinterpret_cast<float *>(smem);
+    const uint32_t q = blockIdx.y;
+    const uint32_t n = sel_count[q];
+    if (blockIdx.x * 64 >= n) return;
+    const uint32_t D = ix.dim;
+    const float *qg = queries + (uint64_t)q * D;
+    for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) qs[i] = qg[i];
+    __syncthreads();
+    const uint32_t j = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    const bool act = j < n;
+    const uint32_t pos = sel_pos[(uint64_t)q * sel_stride + (act ? j : 0)];
+    const bool vec = (D & 3) == 0;
+    float d = distance_group4(qs, ix.vectors + (uint64_t)pos * D, D, ix.metric, sub, vec);
+    if (act && sub == 0) sel_dist[(uint64_t)q * sel_stride + j] = d;
+}
+
+// finalize_results: ascending by (distance, phase-1 order). For the Hamming path phase-1 order is
+// (Hamming distance, scan order) and the selection arrives in scan order, so the sort key is
+// distance key (32 bits) | Hamming (16 bits) | index in the selection (14 bits). When
+// key_is_rank != 0 the selection already arrives in phase-1 order and the middle field is 0.
+// One block per query; dynamic LDS = next_pow2(max selection) u64.
+__global__ void __launch_bounds__(256)
+topk_kernel(IndexDev ix, const uint32_t *sel_pos, const uint32_t *sel_key, const float *sel_dist,
+            uint32_t sel_stride, const uint32_t *sel_count, uint32_t k, uint32_t key_is_rank, uint64_t *out_ids,
+            float *out_dist, uint32_t *out_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = sel_count[q];
+    const uint32_t npad = next_pow2(max(n, 1u));
+    const uint32_t *sp = sel_pos + (uint64_t)q * sel_stride, *sk = sel_key + (uint64_t)q * sel_stride;
+    const float *sd = sel_dist + (uint64_t)q * sel_stride;
+    for (uint32_t i = tid; i < npad; i += blockDim.x) {
+        uint64_t key = ~0ull;
+        if (i < n) {
+            uint32_t mid = key_is_rank ? 0u : (sk[i] & 0xFFFFu);
+            key = ((uint64_t)f32_key(sd[i]) << 30) | ((uint64_t)mid << 14) | i;
+        }
+        skeys[i] = key;
+    }
+    __syncthreads();
+    block_bitonic_sort_u64(skeys, npad);
+    const uint32_t nout = min(n, k);
+    for (uint32_t i = tid; i < k; i += blockDim.x) {
+        if (i < nout) {
+            uint32_t j = (uint32_t)(skeys[i] & 0x3FFFu);
+            out_ids[(uint64_t)q * k + i] = ix.ids[sp[j]];
+            out_dist[(uint64_t)q * k + i] = sd[j];
+        } else {
+            out_ids[(uint64_t)q * k + i] = ~0ull;
+            out_dist[(uint64_t)q * k + i] = __builtin_inff();
+        }
+    }
+    if (tid == 0 && out_count) out_count[q] = nout;
+}
+
+// Phase-1 selection listed in phase-1 order (stage output for parity tests): sorts the scan-order
+// selection by (key, scan order) and gathers pos/key/dist. One block per query.
+__global__ void __launch_bounds__(256)
+selection_order_kernel(const uint32_t *sel_pos, const uint32_t *sel_key, const float *sel_dist, uint32_t sel_stride,
+                       const uint32_t *sel_count, uint32_t key_is_f32, uint64_t *out_pos, uint32_t *out_key,
+                       float *out_dist, uint32_t out_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = sel_count[q];
+    const uint32_t npad = next_pow2(max(n, 1u));
+    for (uint32_t i = tid; i < npad; i += blockDim.x) {
+        uint64_t key = ~0ull;
+        if (i < n) {
+            uint32_t kv = sel_key[(uint64_t)q * sel_stride + i];
+            if (key_is_f32) kv = f32_key(__uint_as_float(kv));
+            key = ((uint64_t)kv << 32) | i;
+        }
+        skeys[i] = key;
+    }
+    __syncthreads();
+    block_bitonic_sort_u64(skeys, npad);
+    for (uint32_t i = tid; i < n && i < out_stride; i += blockDim.x) {
+        uint32_t j = (uint32_t)skeys[i];
+        out_pos[(uint64_t)q * out_stride + i] = sel_pos[(uint64_t)q * sel_stride + j];
+        out_key[(uint64_t)q * out_stride + i] = sel_key[(uint64_t)q * sel_stride + j];
+        if (out_dist) out_dist[(uint64_t)q * out_stride + i] = sel_dist[(uint64_t)q * sel_stride + j];
+    }
+}
+
+} // namespace cuddle

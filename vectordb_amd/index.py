@@ -1,0 +1,225 @@
+"""Host-side mirror of the reference's search interface, on top of the C ABI.
+
+Same names, argument meaning and error behaviour as
+`ClusteredIndex::{build, search, search_with_stats}` (/root/reference/src/index/hierarchical.rs:87,330,831)
+and `ClusteredIndexWithRaBitQ` (src/index/hierarchical_with_rabitq.rs:84,329,809); `search_batch`
+is the batched form the reference only sketches (benches/profile_bench.rs:286-296). All compute
+runs in libcuddle_hip.so on the GPU; there is no CPU path behind these classes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi
+from .flat_index import FlatIndex
+
+UINT64_MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+@dataclass
+class SearchStats:
+    """SearchStats (hierarchical.rs:36-45); batch calls sum over the queries."""
+    total_leaves: int
+    leaves_searched: int
+    total_vectors: int
+    vectors_scanned_binary: int
+    vectors_reranked_full: int
+    tree_depth: int
+    max_candidates: int = 0
+    max_leaves: int = 0
+
+
+class DeviceIndex:
+    """Owns one `cuddle_index` handle (device-resident index + workspace)."""
+
+    def __init__(self, flat: FlatIndex, device_id: int = 0):
+        self.flat = flat.normalised()
+        self._lib = _ffi.lib()
+        self._handle = C.c_void_p(None)
+        desc = self.flat.desc()
+        _ffi.check(self._lib.cuddle_index_create(C.byref(desc), int(device_id), C.byref(self._handle)))
+        self.device_id = int(device_id)
+        self.dim = self.flat.dim
+        self.levels = int(self._lib.cuddle_index_levels(self._handle))
+        self.max_leaf_size = int(self._lib.cuddle_index_max_leaf_size(self._handle))
+        self.max_children = int(self._lib.cuddle_index_max_children(self._handle))
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.cuddle_index_destroy(self._handle)
+            self._handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self._lib.cuddle_index_device_bytes(self._handle))
+
+    def reserve(self, max_queries: int, max_k: int, max_probes: int, max_rerank_k: int) -> None:
+        _ffi.check(self._lib.cuddle_index_reserve(self._handle, max_queries, max_k, max_probes, max_rerank_k))
+
+    # ---- the hot path -------------------------------------------------------------------
+    def search_batch(self, queries: np.ndarray, k: int, probes_per_level: int, rerank_factor: int, flags: int = 0,
+                     want_stats: bool = False):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2:
+            raise ValueError("queries must be [n_queries, dim]")
+        nq, dim = q.shape
+        ids = np.empty((nq, max(k, 0)), dtype=np.uint64)
+        dist = np.empty((nq, max(k, 0)), dtype=np.float32)
+        count = np.empty(nq, dtype=np.uint32)
+        st = _ffi.Stats()
+        _ffi.check(self._lib.cuddle_search_batch(self._handle, _ffi.ptr(q), nq, dim, k, probes_per_level, rerank_factor,
+                                                 flags, _ffi.ptr(ids), _ffi.ptr(dist), _ffi.ptr(count),
+                                                 C.byref(st) if want_stats else None))
+        return (ids, dist, count, st.as_dict()) if want_stats else (ids, dist, count)
+
+    def search_batch_device(self, d_queries, k: int, probes_per_level: int, rerank_factor: int, flags: int = 0,
+                            out_ids=None, out_dist=None, out_count=None, stream: Optional[int] = None):
+        """`d_queries`: float32 CUDA tensor [nq, dim] on this index's device. Enqueues on `stream`
+        (a hipStream_t handle; default: torch's current stream). Returns (ids int64 view of the u64
+        ids, dist, count) tensors; valid once the stream is synchronised."""
+        import torch
+
+        assert d_queries.is_cuda and d_queries.dtype == torch.float32 and d_queries.is_contiguous()
+        nq, dim = d_queries.shape
+        dev = d_queries.device
+        if out_ids is None:
+            out_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        if out_dist is None:
+            out_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        if out_count is None:
+            out_count = torch.empty((nq,), dtype=torch.int32, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        _ffi.check(self._lib.cuddle_search_batch_device(
+            self._handle, C.c_void_p(d_queries.data_ptr()), nq, dim, k, probes_per_level, rerank_factor, flags,
+            C.c_void_p(out_ids.data_ptr()), C.c_void_p(out_dist.data_ptr()), C.c_void_p(out_count.data_ptr()),
+            C.c_void_p(stream)))
+        return out_ids, out_dist, out_count
+
+    def last_stats(self) -> dict:
+        st = _ffi.Stats()
+        _ffi.check(self._lib.cuddle_last_stats(self._handle, C.byref(st)))
+        return st.as_dict()
+
+    def stage_times(self) -> dict:
+        ms = np.zeros(len(_ffi.STAGE_NAMES), dtype=np.float32)
+        _ffi.check(self._lib.cuddle_stage_times(self._handle, _ffi.ptr(ms)))
+        return dict(zip(_ffi.STAGE_NAMES, (float(x) for x in ms)))
+
+    # ---- stage entry points (parity tests) ------------------------------------------------
+    def route_batch(self, queries: np.ndarray, probes_per_level: int, flags: int = 0):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        nq, dim = q.shape
+        stride = max(1, min(probes_per_level, self.flat.n_nodes) * max(self.levels, 1))
+        leaves = np.zeros((nq, stride), dtype=np.uint32)
+        count = np.zeros(nq, dtype=np.uint32)
+        _ffi.check(self._lib.cuddle_route_batch(self._handle, _ffi.ptr(q), nq, dim, probes_per_level, flags,
+                                                _ffi.ptr(leaves), stride, _ffi.ptr(count)))
+        return leaves, count
+
+    def scan_batch(self, queries: np.ndarray, leaves: np.ndarray, leaf_count: np.ndarray):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        nq, dim = q.shape
+        leaves = np.ascontiguousarray(leaves, dtype=np.uint32)
+        leaf_count = np.ascontiguousarray(leaf_count, dtype=np.uint32)
+        sizes = (self.flat.vec_offsets[1:] - self.flat.vec_offsets[:-1]).astype(np.int64)
+        cand = max(1, int(max((sizes[leaves[i, :leaf_count[i]]].sum() for i in range(nq)), default=1)))
+        pos = np.zeros((nq, cand), dtype=np.uint64)
+        key = np.zeros((nq, cand), dtype=np.uint32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        _ffi.check(self._lib.cuddle_scan_batch(self._handle, _ffi.ptr(q), nq, dim, _ffi.ptr(leaves), leaves.shape[1],
+                                               _ffi.ptr(leaf_count), _ffi.ptr(pos), _ffi.ptr(key), cand, _ffi.ptr(cnt)))
+        return pos, key, cnt
+
+    def search_leaves_batch(self, queries: np.ndarray, leaves: np.ndarray, leaf_count: np.ndarray, k: int,
+                            rerank_factor: int, flags: int = 0):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        nq, dim = q.shape
+        leaves = np.ascontiguousarray(leaves, dtype=np.uint32)
+        leaf_count = np.ascontiguousarray(leaf_count, dtype=np.uint32)
+        rk = k * rerank_factor if (flags & _ffi.SEARCH_STATS_VARIANT) else min(k * rerank_factor, 10000)
+        sstride = max(1, rk)
+        ids = np.empty((nq, k), dtype=np.uint64)
+        dist = np.empty((nq, k), dtype=np.float32)
+        count = np.empty(nq, dtype=np.uint32)
+        spos = np.zeros((nq, sstride), dtype=np.uint64)
+        skey = np.zeros((nq, sstride), dtype=np.uint32)
+        sdist = np.zeros((nq, sstride), dtype=np.float32)
+        scount = np.zeros(nq, dtype=np.uint32)
+        _ffi.check(self._lib.cuddle_search_leaves_batch(
+            self._handle, _ffi.ptr(q), nq, dim, _ffi.ptr(leaves), leaves.shape[1], _ffi.ptr(leaf_count), k, rerank_factor,
+            flags, _ffi.ptr(ids), _ffi.ptr(dist), _ffi.ptr(count), _ffi.ptr(spos), _ffi.ptr(skey), _ffi.ptr(sdist),
+            sstride, _ffi.ptr(scount)))
+        return ids, dist, count, spos, skey, sdist, scount
+
+
+class ClusteredIndex:
+    """ClusteredIndex (hierarchical.rs:51-70): hierarchical k-means tree + binary codes."""
+
+    code_kind = "binary"
+
+    def __init__(self, flat: FlatIndex, device_id: int = 0):
+        self.flat = flat
+        self.dev = DeviceIndex(flat, device_id)
+        self.dimension = flat.dim
+
+    @classmethod
+    def build(cls, vectors, vector_file: Optional[str] = None, branching_factor: int = 100, target_leaf_size: int = 100,
+              metric="l2", max_iterations: int = 20, seed: int = 0, device_id: int = 0, build_device: Optional[str] = None):
+        """ClusteredIndex::build (hierarchical.rs:87-174). `vector_file`, when given, receives the
+        raw little-endian f32 rows exactly as MmapVectorStore::create writes them (mmap.rs:59-98)."""
+        from .builder import build_index
+
+        flat = build_index(vectors, branching_factor, target_leaf_size, metric, max_iterations, seed,
+                           code_kind=cls.code_kind, device=build_device)
+        if vector_file is not None:
+            order = np.argsort(flat.ids, kind="stable")
+            flat.vectors[order].astype("<f4").tofile(vector_file)
+        return cls(flat, device_id)
+
+    def __len__(self) -> int:
+        return self.flat.n_vectors
+
+    def search(self, query: Sequence[float], k: int, probes_per_level: int, rerank_factor: int) -> List[Tuple[int, float]]:
+        """search (hierarchical.rs:330-336): [(vector index, distance)] ascending, at most k."""
+        q = np.asarray(query, dtype=np.float32).reshape(1, -1)
+        ids, dist, count = self.dev.search_batch(q, k, probes_per_level, rerank_factor)
+        return [(int(ids[0, i]), float(dist[0, i])) for i in range(int(count[0]))]
+
+    def search_batch(self, queries: np.ndarray, k: int, probes_per_level: int, rerank_factor: int, flags: int = 0):
+        """One search() per row; returns (ids [nq,k] u64 padded with UINT64_MAX, dist [nq,k] f32 padded
+        with +inf, count [nq])."""
+        return self.dev.search_batch(queries, k, probes_per_level, rerank_factor, flags)
+
+    def search_with_stats(self, query: Sequence[float], k: int, probes: int, rerank_factor: int):
+        """search_with_stats (hierarchical.rs:831-938)."""
+        q = np.asarray(query, dtype=np.float32).reshape(1, -1)
+        ids, dist, count, st = self.dev.search_batch(q, k, probes, rerank_factor, _ffi.SEARCH_STATS_VARIANT, want_stats=True)
+        stats = SearchStats(
+            total_leaves=int(self.flat.is_leaf().sum()), leaves_searched=st["leaves_searched"],
+            total_vectors=self.flat.n_vectors, vectors_scanned_binary=st["vectors_scanned"],
+            vectors_reranked_full=st["vectors_reranked"], tree_depth=max(self.dev.levels - 1, 0),
+            max_candidates=st["max_candidates"], max_leaves=st["max_leaves"])
+        return [(int(ids[0, i]), float(dist[0, i])) for i in range(int(count[0]))], stats
+
+    def len(self) -> int:
+        return len(self)
+
+    def is_empty(self) -> bool:
+        return len(self) == 0
+
+
+class ClusteredIndexWithRaBitQ(ClusteredIndex):
+    """ClusteredIndexWithRaBitQ (hierarchical_with_rabitq.rs): same tree, RaBitQ phase-1 codes."""
+
+    code_kind = "rabitq"
