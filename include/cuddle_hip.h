@@ -169,9 +169,11 @@ cuddle_status cuddle_search_batch_device(cuddle_index *idx, const float *d_queri
 
 /* Stats of the most recent search on this handle (synchronises the handle's last stream). */
 cuddle_status cuddle_last_stats(cuddle_index *idx, cuddle_stats *stats);
-/* Per-stage device time in milliseconds of the most recent search that ran with
- * CUDDLE_SEARCH_TIME_STAGES; ms has CUDDLE_STAGE_COUNT entries. Synchronises. */
-cuddle_status cuddle_stage_times(cuddle_index *idx, float *ms);
+/* Per-stage device time in milliseconds, summed over every search on this handle that ran with
+ * CUDDLE_SEARCH_TIME_STAGES since the previous call of this function; ms has CUDDLE_STAGE_COUNT
+ * entries, *n_searches (may be NULL) receives how many searches the sums cover. Waits for the
+ * last of them to finish. */
+cuddle_status cuddle_stage_times(cuddle_index *idx, float *ms, uint32_t *n_searches);
 
 /* ---- stage entry points (host pointers; used by the parity tests) ----------------------- */
 /* distance() for n independent pairs (src/distance/mod.rs:23-34; accumulation order of

@@ -99,7 +99,7 @@ SIGNATURES = {
     "cuddle_search_batch": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(Stats)]),
     "cuddle_search_batch_device": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     "cuddle_last_stats": (_int, [_vp, C.POINTER(Stats)]),
-    "cuddle_stage_times": (_int, [_vp, _vp]),
+    "cuddle_stage_times": (_int, [_vp, _vp, _vp]),
     "cuddle_distance_pairs": (_int, [_vp, _vp, _u64, _u32, _u32, _vp, _int]),
     "cuddle_binary_quantize": (_int, [_vp, _u64, _u32, C.c_float, _vp, _int]),
     "cuddle_hamming_pairs": (_int, [_vp, _vp, _u64, _u32, _vp, _int]),

@@ -171,6 +171,21 @@ def rabitq_encode(vectors: torch.Tensor, rot_t: torch.Tensor, chunk: int = 13107
     return codes, norms, ipoo
 
 
+def pack_binary_codes_torch(x: torch.Tensor, threshold: float, chunk: int = 65536) -> np.ndarray:
+    """pack_binary_codes on a torch device (same bit layout), returned as uint64 numpy."""
+    n, d = x.shape
+    words = (d + 63) // 64
+    out = np.empty((n, words), dtype=np.uint64)
+    sh = torch.arange(32, device=x.device, dtype=torch.int64)
+    for s in range(0, n, chunk):
+        b = torch.zeros((min(chunk, n - s), words * 64), dtype=torch.int64, device=x.device)
+        b[:, :d] = (x[s:s + chunk] > threshold).to(torch.int64)
+        halves = (b.view(-1, words, 2, 32) << sh).sum(-1)          # [m, words, 2] 32-bit halves
+        w64 = halves[..., 0] | (halves[..., 1] << 32)
+        out[s:s + chunk] = w64.cpu().numpy().view(np.uint64)
+    return out
+
+
 def binary_threshold(vectors_f32: np.ndarray) -> float:
     """BinaryQuantizer::from_vectors (binary.rs:122-141), computed by the library's host routine."""
     v = np.ascontiguousarray(vectors_f32, dtype=np.float32)
@@ -225,8 +240,18 @@ def build_index(vectors, branching_factor: int = 100, target_leaf_size: int = 10
     )
     if code_kind == "binary":
         # threshold is defined over the vectors in the caller's order (binary.rs:127-133)
-        fi.threshold = binary_threshold(x.cpu().numpy()) if threshold is None else float(threshold)
-        fi.codes = pack_binary_codes(vec_lc, fi.threshold)
+        # threshold is defined over the vectors in the caller's order (binary.rs:127-133). None: the
+        # reference's sequential single-precision fold (it stops growing once the running sum is
+        # ~2^24 times a typical element, e.g. beyond ~10^7 values); "mean": the exact mean — what
+        # BinaryQuantizer::new(dim, threshold) (binary.rs:114-119) would be given by a careful caller.
+        if threshold is None:
+            fi.threshold = binary_threshold(x.cpu().numpy())
+        elif isinstance(threshold, str):
+            assert threshold == "mean"
+            fi.threshold = float(x.double().mean().item())
+        else:
+            fi.threshold = float(threshold)
+        fi.codes = pack_binary_codes_torch(x[ids_t], fi.threshold) if dev.type != "cpu" else pack_binary_codes(vec_lc, fi.threshold)
     elif code_kind == "rabitq":
         rot = make_rotation(d, seed + 7919)
         fi.rabitq_rot_t = rot

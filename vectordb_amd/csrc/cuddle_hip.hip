@@ -129,6 +129,7 @@ struct cuddle_index {
     std::vector<hipEvent_t> events;
     size_t events_used = 0;
     bool timed = false;
+    uint32_t timed_searches = 0;
     hipStream_t last_stream = nullptr;
     uint32_t last_levels = 0;
     ~cuddle_index() {
@@ -141,6 +142,7 @@ struct cuddle_index {
 };
 
 static constexpr uint32_t kMaxChunk = 4096;
+static constexpr size_t kMaxEvents = 1u << 18; // stage-timing events kept between two cuddle_stage_times() calls
 static constexpr uint32_t kScanThreads = 512;
 static constexpr uint32_t kLdsDistCap = 24576; // u16 distances kept in LDS per query (48 KiB)
 
@@ -572,14 +574,14 @@ static cuddle_status search_device_locked(cuddle_index *ix, const float *dq, uin
     if (probes == 0) return fail(CUDDLE_ERR_BAD_ARG, "probes_per_level must be >= 1");
     uint64_t rerank_k;
     ST_TRY(rerank_k_of(k, rf, flags, rerank_k));
-    ix->timed = (flags & CUDDLE_SEARCH_TIME_STAGES) != 0;
-    ix->events_used = 0;
+    ix->timed = (flags & CUDDLE_SEARCH_TIME_STAGES) != 0 && ix->events_used + 4096 < kMaxEvents;
     ix->last_stream = s;
     ix->last_levels = ix->n_levels;
     HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
     if (nq == 0) return CUDDLE_OK;
     Plan pl;
     ST_TRY(make_plan(ix, nq, k, probes, rerank_k, 0, pl));
+    if (ix->timed) ix->timed_searches++;
     for (uint32_t q0 = 0; q0 < nq; q0 += pl.qc) {
         const uint32_t qc = std::min(pl.qc, nq - q0);
         const float *q = dq + (uint64_t)q0 * dim;
@@ -630,15 +632,19 @@ extern "C" cuddle_status cuddle_last_stats(cuddle_index *idx, cuddle_stats *stat
     return read_stats(idx, stats);
 }
 
-extern "C" cuddle_status cuddle_stage_times(cuddle_index *idx, float *ms) {
+extern "C" cuddle_status cuddle_stage_times(cuddle_index *idx, float *ms, uint32_t *n_searches) {
     if (!idx || !ms) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
     ST_TRY(use_device(idx->device));
     for (int i = 0; i < CUDDLE_STAGE_COUNT; ++i) ms[i] = 0.f;
+    if (n_searches) *n_searches = idx->timed_searches;
+    idx->timed_searches = 0;
     if (idx->events_used == 0) return CUDDLE_OK;
-    HIP_TRY(hipEventSynchronize(idx->events[idx->events_used - 1]));
+    const size_t used = idx->events_used;
+    idx->events_used = 0;
+    HIP_TRY(hipEventSynchronize(idx->events[used - 1]));
     const size_t per = CUDDLE_STAGE_COUNT + 1;
-    for (size_t c = 0; c + per <= idx->events_used; c += per)
+    for (size_t c = 0; c + per <= used; c += per)
         for (int sidx = 0; sidx < CUDDLE_STAGE_COUNT; ++sidx) {
             float t = 0.f;
             HIP_TRY(hipEventElapsedTime(&t, idx->events[c + sidx], idx->events[c + sidx + 1]));

@@ -112,9 +112,14 @@ class DeviceIndex:
         return st.as_dict()
 
     def stage_times(self) -> dict:
+        """Device milliseconds per stage summed over the timed searches since the last call, plus
+        "searches" = how many searches that covers."""
         ms = np.zeros(len(_ffi.STAGE_NAMES), dtype=np.float32)
-        _ffi.check(self._lib.cuddle_stage_times(self._handle, _ffi.ptr(ms)))
-        return dict(zip(_ffi.STAGE_NAMES, (float(x) for x in ms)))
+        n = np.zeros(1, dtype=np.uint32)
+        _ffi.check(self._lib.cuddle_stage_times(self._handle, _ffi.ptr(ms), _ffi.ptr(n)))
+        out = dict(zip(_ffi.STAGE_NAMES, (float(x) for x in ms)))
+        out["searches"] = int(n[0])
+        return out
 
     # ---- stage entry points (parity tests) ------------------------------------------------
     def route_batch(self, queries: np.ndarray, probes_per_level: int, flags: int = 0):
