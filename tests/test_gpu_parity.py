@@ -70,3 +70,34 @@ def test_stage_outputs_match_oracle(gpu):
         assert np.array_equal(skey[i, :scnt[i]], t["sel_key"])
         assert np.array_equal(sdist[i, :scnt[i]].view(np.uint32), t["sel_dist"].view(np.uint32))
         assert np.array_equal(ids[i, :cnt[i]], t["ids"][:t["count"]])
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+def test_mfma_routing_is_exact(gpu, metric):
+    """A level of > 512 nodes shared by all queries goes through the f32-MFMA contraction +
+    exact refinement; leaf lists must equal both the all-exact kernel's and the oracle's."""
+    orc = _oracle()
+    x = clustered(60000, 64, 300, 11, sigma=0.3)
+    from vectordb_amd.builder import build_index
+    fi = build_index(x, 100, 30, metric, 8, seed=3)
+    widths = []
+    cur = list(fi.roots)
+    while cur:
+        widths.append(len(cur))
+        cur = [c for v in cur for c in fi.children[fi.child_offsets[v]:fi.child_offsets[v + 1]]]
+    assert widths[0] <= 100 and widths[1] >= 512, widths
+    dev = DeviceIndex(fi, gpu)
+    q = queries_like(x, 200, 5, noise=0.1)
+    probes = 100
+    lv_mfma, lc_mfma = dev.route_batch(q, probes)
+    lv_exact, lc_exact = dev.route_batch(q, probes, _ffi.SEARCH_ROUTE_EXACT_ONLY)
+    assert np.array_equal(lc_mfma, lc_exact)
+    for i in range(q.shape[0]):
+        assert np.array_equal(lv_mfma[i, :lc_mfma[i]], lv_exact[i, :lc_exact[i]]), i
+    oi = orc.OracleIndex(fi)
+    for i in range(0, q.shape[0], 7):
+        t = oi.search(q[i], 10, probes, 5, trace=True)
+        assert np.array_equal(lv_mfma[i, :lc_mfma[i]], t["leaves"]), i
+    ids, dist, cnt, st = dev.search_batch(q, 10, probes, 5, want_stats=True)
+    assert st["route_fallbacks"] <= q.shape[0] // 10, st
+    _compare_full(fi, dev, q[:40], 10, probes, 5)

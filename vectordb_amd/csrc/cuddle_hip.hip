@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "cuddle_kernels.hpp"
+#include "cuddle_route.hpp"
 
 using namespace cuddle;
 
@@ -88,7 +89,7 @@ struct DevBuf {
 
 struct DevStats { // accumulated on device by stats_accum_kernel
     unsigned long long leaves, scanned, reranked;
-    uint32_t max_cand, max_leaves, pad0, pad1;
+    uint32_t max_cand, max_leaves, fallbacks, pad1;
 };
 
 // Work-space layout of one chunk of queries.
@@ -110,7 +111,21 @@ struct Plan {
     uint16_t *gdist = nullptr;
     uint32_t *sel_pos = nullptr, *sel_key = nullptr, *sel_count = nullptr, *cand_count = nullptr;
     float *sel_dist = nullptr;
+    // MFMA routing
+    uint32_t kc_cap = 0;    // prefilter candidates per query (probes + margin)
+    float *qcent = nullptr, *qsq = nullptr, *rc_dist = nullptr, *rc_max = nullptr;
+    uint32_t *rc_pos = nullptr, *rflag = nullptr;
     size_t bytes = 0;
+};
+
+// Per-level operand of the MFMA routing contraction (see level_table_kernel).
+struct LevelGemm {
+    uint32_t n = 0;            // 0: not built for this level
+    uint32_t *nodes = nullptr; // [n] node ids, breadth-first order
+    float *table = nullptr;    // [n][dim] centroid - mu
+    float *sqn = nullptr;      // [n]
+    float *mu = nullptr;       // [dim]
+    float max_sqn = 0.f;
 };
 
 struct cuddle_index {
@@ -121,6 +136,7 @@ struct cuddle_index {
     uint32_t n_levels = 0, max_children = 0, max_leaf = 0, n_leaves = 0;
     float threshold = 0.f; // BinaryQuantizer::threshold
     std::vector<uint32_t> level_width;
+    std::vector<LevelGemm> lvl;
     DevBuf ws;       // per-chunk work space (Plan)
     DevBuf io;       // staging for the host entry points
     DevStats *d_stats = nullptr;
@@ -144,6 +160,7 @@ struct cuddle_index {
 static constexpr uint32_t kMaxChunk = 4096;
 static constexpr size_t kMaxEvents = 1u << 18; // stage-timing events kept between two cuddle_stage_times() calls
 static constexpr uint32_t kScanThreads = 512;
+static constexpr uint32_t kGemmMinWidth = 512; // narrower levels are routed by the exact kernel
 static constexpr uint32_t kLdsDistCap = 24576; // u16 distances kept in LDS per query (48 KiB)
 
 template <class T>
@@ -216,7 +233,7 @@ extern "C" int cuddle_device_count(void) {
 // index creation
 // ---------------------------------------------------------------------------------------------
 static cuddle_status validate_desc(const cuddle_index_desc *d, std::vector<uint32_t> &depth, uint32_t &n_levels,
-                                   std::vector<uint32_t> &level_width) {
+                                   std::vector<uint32_t> &level_width, std::vector<std::vector<uint32_t>> &level_nodes) {
     if (!d) return fail(CUDDLE_ERR_BAD_ARG, "desc is null");
     if (d->abi_version != CUDDLE_ABI_VERSION) return fail(CUDDLE_ERR_BAD_ARG, "abi_version %u != %u", d->abi_version, CUDDLE_ABI_VERSION);
     if (d->dim == 0 || d->dim > 32768) return fail(CUDDLE_ERR_UNSUPPORTED, "dim %u outside 1..32768", d->dim);
@@ -244,8 +261,10 @@ static cuddle_status validate_desc(const cuddle_index_desc *d, std::vector<uint3
     std::vector<uint32_t> cur(d->roots, d->roots + d->n_roots), nxt;
     uint32_t lvl = 0;
     level_width.clear();
+    level_nodes.clear();
     while (!cur.empty()) {
         level_width.push_back((uint32_t)cur.size());
+        level_nodes.push_back(cur);
         nxt.clear();
         for (uint32_t v : cur) {
             if (v >= n) return fail(CUDDLE_ERR_BAD_INDEX, "node id %u out of range", v);
@@ -264,8 +283,9 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     if (!out) return fail(CUDDLE_ERR_BAD_ARG, "out is null");
     *out = nullptr;
     std::vector<uint32_t> depth, level_width;
+    std::vector<std::vector<uint32_t>> level_nodes;
     uint32_t n_levels = 0;
-    ST_TRY(validate_desc(d, depth, n_levels, level_width));
+    ST_TRY(validate_desc(d, depth, n_levels, level_width, level_nodes));
     ST_TRY(use_device(device_id));
     cuddle_index *ix = new (std::nothrow) cuddle_index();
     if (!ix) return fail(CUDDLE_ERR_OOM, "host allocation failed");
@@ -317,6 +337,33 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     ST_TRY(dev_alloc(ix, (size_t)n, &sqn));
     hipLaunchKernelGGL(centroid_sqnorm_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, centroids, n, D, sqn);
     v.centroid_sqnorm = sqn;
+
+    // operands of the MFMA routing contraction, for every level wide enough to use it
+    ix->lvl.assign(n_levels, LevelGemm());
+    if (D % 4 == 0) {
+        for (uint32_t l = 0; l < n_levels; ++l) {
+            const std::vector<uint32_t> &nodes = level_nodes[l];
+            if (nodes.size() < kGemmMinWidth) continue;
+            LevelGemm &g = ix->lvl[l];
+            std::vector<float> mu(D, 0.f);
+            if (d->metric == CUDDLE_METRIC_L2) {
+                std::vector<double> acc(D, 0.0);
+                for (uint32_t v2 : nodes)
+                    for (uint32_t i = 0; i < D; ++i) acc[i] += d->centroids[(size_t)v2 * D + i];
+                for (uint32_t i = 0; i < D; ++i) mu[i] = (float)(acc[i] / (double)nodes.size());
+            }
+            ST_TRY(upload(ix, nodes.data(), nodes.size(), &g.nodes));
+            ST_TRY(upload(ix, mu.data(), (size_t)D, &g.mu));
+            ST_TRY(dev_alloc(ix, nodes.size() * (size_t)D, &g.table));
+            ST_TRY(dev_alloc(ix, nodes.size(), &g.sqn));
+            hipLaunchKernelGGL(level_table_kernel, dim3(((uint32_t)nodes.size() + 127) / 128), dim3(128), 0, 0, centroids,
+                               g.nodes, (uint32_t)nodes.size(), D, g.mu, g.table, g.sqn);
+            std::vector<float> h(nodes.size());
+            HIP_TRY(hipMemcpy(h.data(), g.sqn, nodes.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (float x : h) g.max_sqn = std::max(g.max_sqn, x);
+            g.n = (uint32_t)nodes.size();
+        }
+    }
 
     uint32_t *d_pos_leaf = nullptr;
     if (N) {
@@ -449,6 +496,9 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     size_t o_gd = carve(qc * (size_t)pl.cstride * 4); // u16 Hamming or f32 estimates
     size_t o_sp = carve(qc * pl.sstride * 4), o_sk = carve(qc * pl.sstride * 4), o_sd = carve(qc * pl.sstride * 4);
     size_t o_sc = carve(qc * 4), o_cc = carve(qc * 4);
+    pl.kc_cap = (uint32_t)align_up((size_t)pl.probes + std::max<uint32_t>(64, pl.probes / 4), 64);
+    size_t o_qcent = carve(qc * v.dim * 4), o_qsq = carve(qc * 4);
+    size_t o_rcp = carve(qc * pl.kc_cap * 4), o_rcd = carve(qc * pl.kc_cap * 4), o_rcm = carve(qc * 4), o_rfl = carve(qc * 4);
     pl.bytes = off;
     ST_TRY(ix->ws.ensure(pl.bytes));
     char *b = static_cast<char *>(ix->ws.p);
@@ -460,6 +510,9 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     pl.gdist = (uint16_t *)(b + o_gd);
     pl.sel_pos = (uint32_t *)(b + o_sp); pl.sel_key = (uint32_t *)(b + o_sk); pl.sel_dist = (float *)(b + o_sd);
     pl.sel_count = (uint32_t *)(b + o_sc); pl.cand_count = (uint32_t *)(b + o_cc);
+    pl.qcent = (float *)(b + o_qcent); pl.qsq = (float *)(b + o_qsq);
+    pl.rc_pos = (uint32_t *)(b + o_rcp); pl.rc_dist = (float *)(b + o_rcd); pl.rc_max = (float *)(b + o_rcm);
+    pl.rflag = (uint32_t *)(b + o_rfl);
     return CUDDLE_OK;
 }
 
@@ -492,10 +545,6 @@ static uint32_t host_next_pow2(uint32_t v) {
     return p;
 }
 
-static size_t route_select_lds_bytes(uint32_t scap) {
-    return (size_t)scap * 8 + 256 * 4 + 32 * 4 + 8 * 4 + 2 * ((size_t)scap + 1) * 4 + 16;
-}
-
 static cuddle_status launch_quantize(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, hipStream_t s) {
     const IndexDev &v = ix->dev;
     if (v.code_kind == CUDDLE_CODE_BINARY) {
@@ -510,6 +559,9 @@ static cuddle_status launch_quantize(cuddle_index *ix, const Plan &pl, const flo
 }
 
 // All tree levels (hierarchical.rs:349-423). Leaves end up in pl.leaves / pl.lcount.
+// A level whose frontier is the same for every query (all earlier levels kept all their nodes)
+// and wider than probes goes through the MFMA contraction + exact refinement; every other level
+// through the exact kernels. Both give the same selection.
 static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, uint32_t flags,
                                   hipStream_t s) {
     const IndexDev &v = ix->dev;
@@ -518,16 +570,39 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                        pl.frontier[0], pl.fstride, pl.fcount[0], pl.lcount, nq);
     int cur = 0;
     uint64_t fb = v.n_roots;
+    bool shared = !stats;
     for (uint32_t l = 0; l < ix->n_levels; ++l) {
         fb = std::min<uint64_t>(fb, ix->level_width[l]);
         const uint32_t bound = (uint32_t)std::max<uint64_t>(fb, 1);
-        hipLaunchKernelGGL(route_dist_kernel, dim3((bound + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
-                           pl.frontier[cur], pl.fstride, pl.fcount[cur], pl.fdist, stats);
+        const bool keep_all = !stats && bound <= pl.probes;
         const uint32_t scap = std::min(kSortCap, host_next_pow2(bound));
+        const LevelGemm &g = ix->lvl[l];
+        const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound;
+        const uint32_t *only = nullptr;
+        if (use_gemm) {
+            const uint32_t n = g.n, kc = std::min(n, pl.kc_cap);
+            hipLaunchKernelGGL(center_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, pl.qcent, pl.qsq);
+            const uint32_t gx = (n + kGemmBN - 1) / kGemmBN, gy = (nq + kGemmBM - 1) / kGemmBM;
+            hipLaunchKernelGGL(route_gemm_kernel, dim3(8 * ((gx + 7) / 8) * gy), dim3(256), kGemmLdsBytes, s, pl.qcent, pl.qsq,
+                               g.table, g.sqn, nq, n, v.dim, v.metric, pl.fdist, pl.fstride, gx, gy);
+            hipLaunchKernelGGL(route_prefilter_kernel, dim3(nq), dim3(256), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,
+                               pl.kc_cap, pl.rc_max);
+            hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
+                               g.nodes, pl.rc_pos, pl.kc_cap, kc, pl.rc_dist);
+            hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(kc), pl.probes), s,
+                               v, g.nodes, n, pl.rc_pos, pl.rc_dist, pl.kc_cap, kc, pl.rc_max, pl.qsq, g.max_sqn, pl.probes,
+                               pl.frontier[cur ^ 1], pl.fstride, pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,
+                               pl.rflag, &ix->d_stats->fallbacks);
+            only = pl.rflag; // queries whose selection could not be proven exact fall through to the exact kernels
+        }
+        if (!keep_all)
+            hipLaunchKernelGGL(route_dist_kernel, dim3((bound + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
+                               pl.frontier[cur], pl.fstride, pl.fcount[cur], pl.fdist, pl.probes, stats, only);
         hipLaunchKernelGGL(route_select_kernel, dim3(nq), dim3(256), route_select_lds_bytes(scap), s, v, pl.frontier[cur],
                            pl.fstride, pl.fcount[cur], pl.fdist, pl.probes, stats, scap, pl.frontier[cur ^ 1],
-                           pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount);
+                           pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount, only);
         cur ^= 1;
+        shared = shared && keep_all;
         fb = std::min<uint64_t>(fb, pl.probes) * std::max<uint32_t>(ix->max_children, 1);
     }
     HIP_TRY(hipGetLastError());
@@ -621,7 +696,7 @@ static cuddle_status read_stats(cuddle_index *ix, cuddle_stats *st) {
     st->max_candidates = h.max_cand;
     st->max_leaves = h.max_leaves;
     st->tree_levels = ix->last_levels;
-    st->route_fallbacks = 0;
+    st->route_fallbacks = h.fallbacks;
     return CUDDLE_OK;
 }
 

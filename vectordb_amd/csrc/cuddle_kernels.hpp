@@ -380,176 +380,6 @@ __global__ void relayout_rabitq_kernel(const uint32_t *src, uint32_t *dst, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// routing (hierarchical.rs:349-423)
-// ---------------------------------------------------------------------------------------------
-
-// Level start: frontier = root_ids for every query (hierarchical.rs:346).
-__global__ void route_init_kernel(const uint32_t *roots, uint32_t n_roots, uint32_t *frontier, uint32_t fstride,
-                                  uint32_t *fcount, uint32_t *lcount, uint32_t nq) {
-    uint32_t q = blockIdx.y;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    if (i < n_roots) frontier[(uint64_t)q * fstride + i] = roots[i];
-    if (i == 0) {
-        fcount[q] = n_roots;
-        lcount[q] = 0;
-    }
-}
-
-// Exact distances query -> frontier centroids, in the arithmetic search() uses for that
-// frontier size (hierarchical.rs:355-391): n > 100 or n < 4: distance(metric) per node;
-// 4 <= n <= 100: l2_squared_batch, i.e. batch4 arithmetic for the first 4*floor(n/4) nodes and
-// l2_squared for the rest, whatever the metric. stats_variant: always distance(metric) (:868-886).
-// grid = (ceil(fstride/64), nq), block = 256: one 4-lane group per (query, node).
-__global__ void __launch_bounds__(256)
-route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, uint32_t fstride,
-                  const uint32_t *fcount, float *fdist, uint32_t stats_variant) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *qs = reinterpret_cast<float *>(smem);
-    const uint32_t q = blockIdx.y;
-    const uint32_t n = fcount[q];
-    const uint32_t D = ix.dim;
-    const bool small = !stats_variant && n >= 4 && n <= 100;
-    if (small ? (blockIdx.x != 0) : (blockIdx.x * 64 >= n)) return;
-    const float *qg = queries + (uint64_t)q * D;
-    for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) qs[i] = qg[i];
-    __syncthreads();
-    const uint32_t *fr = frontier + (uint64_t)q * fstride;
-    float *fd = fdist + (uint64_t)q * fstride;
-    if (small) {
-        uint32_t j = threadIdx.x;
-        if (j < n) {
-            const float *c = ix.centroids + (uint64_t)fr[j] * D;
-            fd[j] = (j < (n & ~3u)) ? l2_batch4_serial(qs, c, D) : neon16_serial<true>(qs, c, D);
-        }
-        return;
-    }
-    const uint32_t j = blockIdx.x * 64 + (threadIdx.x >> 2);
-    const uint32_t sub = threadIdx.x & 3;
-    const bool act = j < n;
-    const uint32_t node = fr[act ? j : 0];
-    const bool vec = (D & 3) == 0;
-    float d = distance_group4(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, vec);
-    if (act && sub == 0) fd[j] = d;
-}
-
-// Per query: choose the nodes to descend into (hierarchical.rs:393-408), split them into leaves
-// and internal nodes (:411-413), append the leaves (:416) and build the next frontier from the
-// internal nodes' children (:419-422). One block per query.
-//   n <= probes (and not stats_variant): all nodes, frontier order.
-//   otherwise: the min(n, probes) smallest by (distance, frontier position), in that order.
-// scap (a power of two <= kSortCap) bounds the sorted set: min(n, probes) <= scap whenever n > scap
-// is possible. Dynamic LDS: scap u64 keys + 256 u32 histogram + 2 (scap+1) u32 counters + scratch.
-__global__ void __launch_bounds__(256)
-route_select_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, const uint32_t *fcount,
-                    const float *fdist, uint32_t probes, uint32_t stats_variant, uint32_t scap,
-                    uint32_t *next_frontier, uint32_t *next_fcount, uint32_t *leaves, uint32_t lstride,
-                    uint32_t *lcount) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);                 // [scap]
-    uint32_t *hist = reinterpret_cast<uint32_t *>(skeys + scap);         // [256]
-    uint32_t *wtmp = hist + 256;                                         // [2 * waves]
-    uint32_t *misc = wtmp + 32;                                          // [8]
-    uint32_t *cnt_leaf = misc + 8;                                       // [scap + 1]
-    uint32_t *cnt_child = cnt_leaf + scap + 1;                           // [scap + 1]
-    const uint32_t q = blockIdx.x;
-    const uint32_t n = fcount[q];
-    const uint32_t tid = threadIdx.x;
-    if (n == 0) {
-        if (tid == 0) next_fcount[q] = 0;
-        return;
-    }
-    const uint32_t *fr = frontier + (uint64_t)q * fstride;
-    const float *fd = fdist + (uint64_t)q * fstride;
-    uint32_t nsel;
-    const bool keep_all = !stats_variant && n <= probes;
-    if (keep_all) {
-        nsel = n; // n <= this level's bound <= scap
-        for (uint32_t i = tid; i < n; i += blockDim.x) skeys[i] = i;
-        __syncthreads();
-    } else {
-        nsel = min(n, probes);
-        uint32_t npad;
-        if (n <= scap) {
-            npad = next_pow2(n);
-            for (uint32_t i = tid; i < npad; i += blockDim.x)
-                skeys[i] = i < n ? (((uint64_t)f32_key(fd[i]) << 32) | i) : ~0ull;
-            __syncthreads();
-        } else {
-            // radix select of the nsel-th smallest 32-bit key, 8 bits per pass
-            uint32_t prefix = 0, want = nsel; // want-th smallest (1-based) among keys matching prefix
-            for (int shift = 24; shift >= 0; shift -= 8) {
-                for (uint32_t i = tid; i < 256; i += blockDim.x) hist[i] = 0;
-                __syncthreads();
-                const uint32_t himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
-                for (uint32_t i = tid; i < n; i += blockDim.x) {
-                    uint32_t kv = f32_key(fd[i]);
-                    if ((kv & himask) == prefix) atomicAdd(&hist[(kv >> shift) & 255u], 1u);
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    uint32_t cum = 0, b = 0;
-                    for (; b < 256; ++b) {
-                        if (cum + hist[b] >= want) break;
-                        cum += hist[b];
-                    }
-                    misc[0] = prefix | (b << shift);
-                    misc[1] = want - cum;
-                }
-                __syncthreads();
-                prefix = misc[0];
-                want = misc[1];
-                __syncthreads();
-            }
-            // prefix = threshold key T; `want` of the items with key == T are taken, in index order
-            const uint32_t T = prefix, budget = want;
-            ordered_threshold_compact(
-                n, T, budget, [&](uint32_t i) { return f32_key(fd[i]); },
-                [&](uint32_t i, uint32_t kv, uint32_t rank) { skeys[rank] = ((uint64_t)kv << 32) | i; }, wtmp);
-            npad = next_pow2(nsel);
-            for (uint32_t i = nsel + tid; i < npad; i += blockDim.x) skeys[i] = ~0ull;
-            __syncthreads();
-        }
-        block_bitonic_sort_u64(skeys, npad);
-    }
-    // skeys[0..nsel): low 32 bits = frontier position of the chosen nodes, in order.
-    for (uint32_t i = tid; i < nsel; i += blockDim.x) {
-        uint32_t node = fr[(uint32_t)skeys[i]];
-        uint32_t cc = ix.child_off[node + 1] - ix.child_off[node];
-        cnt_leaf[i] = cc == 0 ? 1u : 0u;
-        cnt_child[i] = cc;
-    }
-    __syncthreads();
-    wave0_exclusive_scan_lds(cnt_leaf, nsel);
-    __syncthreads();
-    wave0_exclusive_scan_lds(cnt_child, nsel);
-    __syncthreads();
-    const uint32_t lbase = lcount[q];
-    uint32_t *lv = leaves + (uint64_t)q * lstride;
-    uint32_t *nf = next_frontier + (uint64_t)q * fstride;
-    // one wave per chosen node: leaves are appended, children copied with coalesced stores
-    const uint32_t nw = blockDim.x >> 6, w = tid >> 6, lane = tid & 63;
-    for (uint32_t i = w; i < nsel; i += nw) {
-        uint32_t node = fr[(uint32_t)skeys[i]];
-        uint32_t cb = ix.child_off[node], ce = ix.child_off[node + 1];
-        if (cb == ce) {
-            if (lane == 0) {
-                uint32_t slot = lbase + cnt_leaf[i];
-                if (slot < lstride) lv[slot] = node;
-            }
-        } else {
-            uint32_t ob = cnt_child[i];
-            for (uint32_t c = lane; c < ce - cb; c += 64)
-                if (ob + c < fstride) nf[ob + c] = ix.children[cb + c];
-        }
-    }
-    if (tid == 0) {
-        lcount[q] = min(lbase + cnt_leaf[nsel], lstride);
-        next_fcount[q] = min(cnt_child[nsel], fstride);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Hamming leaf scan + phase-1 selection (hierarchical.rs:591-655)
 // ---------------------------------------------------------------------------------------------
 

@@ -1,0 +1,477 @@
+// cuddle_route.hpp — centroid routing kernels (reference: src/index/hierarchical.rs:349-423).
+//
+// Two ways to evaluate one tree level for a batch of queries, with bit-identical results:
+//
+//  * exact path (any level): route_dist_kernel computes every query->centroid distance in the
+//    arithmetic the reference uses for that frontier size, route_select_kernel picks the nodes.
+//
+//  * MFMA path (a level whose frontier is the same node list for every query and wider than
+//    probes_per_level): the query x centroid contraction runs on the f32 matrix cores
+//    (v_mfma_f32_32x32x2_f32) with precomputed squared norms and gives an *approximate* distance
+//    d~ for every (query, node); the probes + margin smallest d~ per query are then re-evaluated
+//    exactly, sorted, and accepted only if the error bound proves that no unselected node can
+//    belong to the exact top `probes`. Queries that fail the proof are re-routed by the exact path.
+#pragma once
+
+#include "cuddle_kernels.hpp"
+
+namespace cuddle {
+
+// ---------------------------------------------------------------------------------------------
+// shared pieces
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float f32_from_key(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// Radix select over n keys (key(i) -> u32): returns the value T of the want-th smallest key
+// (1-based) and, in `budget`, how many of the keys equal to T belong to the `want` smallest.
+// hist: 256 u32 of LDS, misc: 2 u32 of LDS. All threads of the block call.
+template <class KeyFn>
+__device__ __forceinline__ uint32_t block_radix_select(uint32_t n, uint32_t want, KeyFn key, uint32_t *hist,
+                                                       uint32_t *misc, uint32_t &budget) {
+    uint32_t prefix = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        const uint32_t himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            uint32_t kv = key(i);
+            if ((kv & himask) == prefix) atomicAdd(&hist[(kv >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t cum = 0, b = 0;
+            for (; b < 255; ++b) {
+                if (cum + hist[b] >= want) break;
+                cum += hist[b];
+            }
+            misc[0] = prefix | (b << shift);
+            misc[1] = want - cum;
+        }
+        __syncthreads();
+        prefix = misc[0];
+        want = misc[1];
+        __syncthreads();
+    }
+    budget = want;
+    return prefix;
+}
+
+// Split the chosen nodes into leaves and internal nodes (hierarchical.rs:411-413), append the
+// leaves to the query's leaf list (:416) and write the children of the internal nodes, in order,
+// as the next frontier (:419-422). skeys[i] (low 32 bits) = position in `fr` of the i-th chosen
+// node. cnt_leaf / cnt_child: nsel + 1 u32 of LDS each. All threads of the block call.
+__device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t *fr, const uint64_t *skeys,
+                                             uint32_t nsel, uint32_t *cnt_leaf, uint32_t *cnt_child, uint32_t *nf,
+                                             uint32_t fstride, uint32_t *next_fcount_q, uint32_t *lv, uint32_t lstride,
+                                             uint32_t *lcount_q) {
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < nsel; i += blockDim.x) {
+        uint32_t node = fr[(uint32_t)skeys[i]];
+        uint32_t cc = ix.child_off[node + 1] - ix.child_off[node];
+        cnt_leaf[i] = cc == 0 ? 1u : 0u;
+        cnt_child[i] = cc;
+    }
+    __syncthreads();
+    wave0_exclusive_scan_lds(cnt_leaf, nsel);
+    __syncthreads();
+    wave0_exclusive_scan_lds(cnt_child, nsel);
+    __syncthreads();
+    const uint32_t lbase = *lcount_q;
+    // one wave per chosen node: leaves are appended, children copied with coalesced stores
+    const uint32_t nw = blockDim.x >> 6, w = tid >> 6, lane = tid & 63;
+    for (uint32_t i = w; i < nsel; i += nw) {
+        uint32_t node = fr[(uint32_t)skeys[i]];
+        uint32_t cb = ix.child_off[node], ce = ix.child_off[node + 1];
+        if (cb == ce) {
+            if (lane == 0) {
+                uint32_t slot = lbase + cnt_leaf[i];
+                if (slot < lstride) lv[slot] = node;
+            }
+        } else {
+            uint32_t ob = cnt_child[i];
+            for (uint32_t c = lane; c < ce - cb; c += 64)
+                if (ob + c < fstride) nf[ob + c] = ix.children[cb + c];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        *lcount_q = min(lbase + cnt_leaf[nsel], lstride);
+        *next_fcount_q = min(cnt_child[nsel], fstride);
+    }
+}
+
+// Level start: frontier = root_ids for every query (hierarchical.rs:346).
+__global__ void route_init_kernel(const uint32_t *roots, uint32_t n_roots, uint32_t *frontier, uint32_t fstride,
+                                  uint32_t *fcount, uint32_t *lcount, uint32_t nq) {
+    uint32_t q = blockIdx.y;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    if (i < n_roots) frontier[(uint64_t)q * fstride + i] = roots[i];
+    if (i == 0) {
+        fcount[q] = n_roots;
+        lcount[q] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact path
+// ---------------------------------------------------------------------------------------------
+
+// Exact distances query -> frontier centroids, in the arithmetic search() uses for that
+// frontier size (hierarchical.rs:355-391): n > 100 or n < 4: distance(metric) per node;
+// 4 <= n <= 100: l2_squared_batch, i.e. batch4 arithmetic for the first 4*floor(n/4) nodes and
+// l2_squared for the rest, whatever the metric. stats_variant: always distance(metric) (:868-886).
+// Nothing is computed for a query whose nodes are all kept (n <= probes, :395-397).
+// only_flag != null: only queries with only_flag[q] != 0 are processed.
+// grid = (ceil(bound/64), nq), block = 256: one 4-lane group per (query, node).
+__global__ void __launch_bounds__(256)
+route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, uint32_t fstride,
+                  const uint32_t *fcount, float *fdist, uint32_t probes, uint32_t stats_variant,
+                  const uint32_t *only_flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *qs = reinterpret_cast<float *>(smem);
+    const uint32_t q = blockIdx.y;
+    if (only_flag && !only_flag[q]) return;
+    const uint32_t n = fcount[q];
+    if (!stats_variant && n <= probes) return;
+    const uint32_t D = ix.dim;
+    const bool small = !stats_variant && n >= 4 && n <= 100;
+    if (small ? (blockIdx.x != 0) : (blockIdx.x * 64 >= n)) return;
+    const float *qg = queries + (uint64_t)q * D;
+    for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) qs[i] = qg[i];
+    __syncthreads();
+    const uint32_t *fr = frontier + (uint64_t)q * fstride;
+    float *fd = fdist + (uint64_t)q * fstride;
+    if (small) {
+        uint32_t j = threadIdx.x;
+        if (j < n) {
+            const float *c = ix.centroids + (uint64_t)fr[j] * D;
+            fd[j] = (j < (n & ~3u)) ? l2_batch4_serial(qs, c, D) : neon16_serial<true>(qs, c, D);
+        }
+        return;
+    }
+    const uint32_t j = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const uint32_t sub = threadIdx.x & 3;
+    const bool act = j < n;
+    const uint32_t node = fr[act ? j : 0];
+    const bool vec = (D & 3) == 0;
+    float d = distance_group4(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, vec);
+    if (act && sub == 0) fd[j] = d;
+}
+
+inline size_t route_select_lds_bytes(uint32_t scap) {
+    return (size_t)scap * 8 + 256 * 4 + 32 * 4 + 8 * 4 + 2 * ((size_t)scap + 1) * 4 + 16;
+}
+
+// Per query: choose the nodes to descend into (hierarchical.rs:393-408) and expand them.
+//   n <= probes (and not stats_variant): all nodes, frontier order.
+//   otherwise: the min(n, probes) smallest by (distance, frontier position), in that order.
+// scap (a power of two <= kSortCap) bounds the sorted set: min(n, probes) <= scap whenever n > scap
+// is possible. One block per query; dynamic LDS = route_select_lds_bytes(scap).
+__global__ void __launch_bounds__(256)
+route_select_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, const uint32_t *fcount,
+                    const float *fdist, uint32_t probes, uint32_t stats_variant, uint32_t scap,
+                    uint32_t *next_frontier, uint32_t *next_fcount, uint32_t *leaves, uint32_t lstride,
+                    uint32_t *lcount, const uint32_t *only_flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);                 // [scap]
+    uint32_t *hist = reinterpret_cast<uint32_t *>(skeys + scap);         // [256]
+    uint32_t *wtmp = hist + 256;                                         // [2 * waves]
+    uint32_t *misc = wtmp + 32;                                          // [8]
+    uint32_t *cnt_leaf = misc + 8;                                       // [scap + 1]
+    uint32_t *cnt_child = cnt_leaf + scap + 1;                           // [scap + 1]
+    const uint32_t q = blockIdx.x;
+    if (only_flag && !only_flag[q]) return;
+    const uint32_t n = fcount[q];
+    const uint32_t tid = threadIdx.x;
+    if (n == 0) {
+        if (tid == 0) next_fcount[q] = 0;
+        return;
+    }
+    const uint32_t *fr = frontier + (uint64_t)q * fstride;
+    const float *fd = fdist + (uint64_t)q * fstride;
+    uint32_t nsel;
+    const bool keep_all = !stats_variant && n <= probes;
+    if (keep_all) {
+        nsel = n; // n <= this level's bound <= scap
+        for (uint32_t i = tid; i < n; i += blockDim.x) skeys[i] = i;
+        __syncthreads();
+    } else {
+        nsel = min(n, probes);
+        uint32_t npad;
+        if (n <= scap) {
+            npad = next_pow2(n);
+            for (uint32_t i = tid; i < npad; i += blockDim.x)
+                skeys[i] = i < n ? (((uint64_t)f32_key(fd[i]) << 32) | i) : ~0ull;
+            __syncthreads();
+        } else {
+            uint32_t budget;
+            const uint32_t T = block_radix_select(n, nsel, [&](uint32_t i) { return f32_key(fd[i]); }, hist, misc, budget);
+            ordered_threshold_compact(
+                n, T, budget, [&](uint32_t i) { return f32_key(fd[i]); },
+                [&](uint32_t i, uint32_t kv, uint32_t rank) { skeys[rank] = ((uint64_t)kv << 32) | i; }, wtmp);
+            npad = next_pow2(nsel);
+            for (uint32_t i = nsel + tid; i < npad; i += blockDim.x) skeys[i] = ~0ull;
+            __syncthreads();
+        }
+        block_bitonic_sort_u64(skeys, npad);
+    }
+    route_expand(ix, fr, skeys, nsel, cnt_leaf, cnt_child, next_frontier + (uint64_t)q * fstride, fstride,
+                 next_fcount + q, leaves + (uint64_t)q * lstride, lstride, lcount + q);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA path
+// ---------------------------------------------------------------------------------------------
+
+// Per-level table for the contraction (built once per index): row j = centroid of the j-th node
+// of the level (breadth-first order = the frontier order every query sees when all earlier
+// levels keep all their nodes) minus mu (L2: the level's mean centroid, which keeps the norms and
+// so the rounding error of the norm expansion small; other metrics: mu = 0), plus its squared
+// norm as a fused-multiply-add chain.
+__global__ void level_table_kernel(const float *centroids, const uint32_t *level_nodes, uint32_t n, uint32_t dim,
+                                   const float *mu, float *table, float *sqn) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float *c = centroids + (uint64_t)level_nodes[j] * dim;
+    float *t = table + (uint64_t)j * dim;
+    float s = 0.f;
+    for (uint32_t i = 0; i < dim; ++i) {
+        float v = c[i] - mu[i];
+        t[i] = v;
+        s = __builtin_fmaf(v, v, s);
+    }
+    sqn[j] = s;
+}
+
+// q' = q - mu and |q'|^2 for every query of the batch (one wave per query).
+__global__ void __launch_bounds__(256)
+center_queries_kernel(const float *queries, const float *mu, uint32_t nq, uint32_t dim, float *out, float *sqn) {
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    float s = 0.f;
+    for (uint32_t i = lane; i < dim; i += 64) {
+        float v = queries[(uint64_t)q * dim + i] - mu[i];
+        out[(uint64_t)q * dim + i] = v;
+        s = __builtin_fmaf(v, v, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) sqn[q] = s;
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32;
+constexpr int kGemmLdsRow = 20; // 16 floats of one (row, k-parity) + 4 pad: conflict-free ds_read_b128
+constexpr size_t kGemmLdsBytes = 2 /*A,B*/ * 2 /*parity*/ * 128 * kGemmLdsRow * sizeof(float);
+
+// Approximate distances of every query to every node of one level:
+//   S = A * B^T on the f32 matrix cores (A = centred queries [M][K], B = level table [N][K]),
+//   L2:     d~ = (|a|^2 + |b|^2) - 2 S
+//   DOT:    d~ = -S
+//   COSINE: d~ = 1 - S / (|a| |b|)
+// Block tile 128 x 128, K step 32, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles of
+// 32 x 32 (v_mfma_f32_32x32x2_f32: lane l supplies A[row l&31][k = l>>5] and B[k = l>>5][col l&31]).
+// LDS image per operand: [k parity h][row][s] with k = 2s + h, so a lane reads its 16 k-values of
+// a K step with four ds_read_b128. Global tiles are prefetched into registers one K step ahead.
+// Blocks are numbered so that the row blocks of one column panel share an XCD (its L2 keeps the
+// panel of B): id % 8 selects the XCD, panels x = 8 * xl + xcd belong to XCD xcd.
+// K must be a multiple of 4. out: [M][ostride].
+__global__ void __launch_bounds__(256)
+route_gemm_kernel(const float *A, const float *Asq, const float *B, const float *Bsq, uint32_t M, uint32_t N,
+                  uint32_t K, uint32_t metric, float *out, uint32_t ostride, uint32_t gx, uint32_t gy) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *As = reinterpret_cast<float *>(smem);            // [2][128][20]
+    float *Bs = As + 2 * 128 * kGemmLdsRow;                 // [2][128][20]
+    const uint32_t id = blockIdx.x;
+    const uint32_t xcd = id & 7, local = id >> 3;
+    const uint32_t bx = (local / gy) * 8 + xcd, by = local % gy;
+    if (bx >= gx) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t wr = w >> 1, wc = w & 1, r = lane & 31, h = lane >> 5;
+    // global -> register staging: thread covers rows (tid>>3) + 32 i, floats 4 (tid&7) .. +3
+    const uint32_t lr = tid >> 3, lc4 = tid & 7;
+    const float *ga[4], *gb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t ra = min(by * kGemmBM + lr + 32 * i, M - 1), rb = min(bx * kGemmBN + lr + 32 * i, N - 1);
+        ga[i] = A + (uint64_t)ra * K + 4 * lc4;
+        gb[i] = B + (uint64_t)rb * K + 4 * lc4;
+    }
+    float4 pa[4], pb[4];
+    auto load_tile = [&](uint32_t k0) {
+        const bool in = k0 + 4 * lc4 < K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pa[i] = in ? *reinterpret_cast<const float4 *>(ga[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pb[i] = in ? *reinterpret_cast<const float4 *>(gb[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t row = lr + 32 * i;
+            float *a0 = As + (0 * 128 + row) * kGemmLdsRow + 2 * lc4, *a1 = As + (1 * 128 + row) * kGemmLdsRow + 2 * lc4;
+            float *b0 = Bs + (0 * 128 + row) * kGemmLdsRow + 2 * lc4, *b1 = Bs + (1 * 128 + row) * kGemmLdsRow + 2 * lc4;
+            *reinterpret_cast<float2 *>(a0) = make_float2(pa[i].x, pa[i].z);
+            *reinterpret_cast<float2 *>(a1) = make_float2(pa[i].y, pa[i].w);
+            *reinterpret_cast<float2 *>(b0) = make_float2(pb[i].x, pb[i].z);
+            *reinterpret_cast<float2 *>(b1) = make_float2(pb[i].y, pb[i].w);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+    load_tile(0);
+    for (uint32_t k0 = 0; k0 < K; k0 += kGemmBK) {
+        __syncthreads(); // previous step's LDS reads are done
+        store_tile();
+        __syncthreads();
+        if (k0 + kGemmBK < K) load_tile(k0 + kGemmBK);
+        float4 fa[2][4], fb[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float4 *pa4 = reinterpret_cast<const float4 *>(As + (h * 128 + wr * 64 + t * 32 + r) * kGemmLdsRow);
+            const float4 *pb4 = reinterpret_cast<const float4 *>(Bs + (h * 128 + wc * 64 + t * 32 + r) * kGemmLdsRow);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                fa[t][s4] = pa4[s4];
+                fb[t][s4] = pb4[s4];
+            }
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a0 = e == 0 ? fa[0][s4].x : e == 1 ? fa[0][s4].y : e == 2 ? fa[0][s4].z : fa[0][s4].w;
+                float a1 = e == 0 ? fa[1][s4].x : e == 1 ? fa[1][s4].y : e == 2 ? fa[1][s4].z : fa[1][s4].w;
+                float b0 = e == 0 ? fb[0][s4].x : e == 1 ? fb[0][s4].y : e == 2 ? fb[0][s4].z : fb[0][s4].w;
+                float b1 = e == 0 ? fb[1][s4].x : e == 1 ? fb[1][s4].y : e == 2 ? fb[1][s4].z : fb[1][s4].w;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const uint32_t gn = bx * kGemmBN + wc * 64 + nt * 32 + r;
+            if (gn >= N) continue;
+            const float bs = Bsq[gn];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t gm = by * kGemmBM + wr * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (gm >= M) continue;
+                const float s = acc[mt][nt][e], as = Asq[gm];
+                float d;
+                if (metric == kMetricL2) d = __builtin_fmaf(-2.0f, s, as + bs);
+                else if (metric == kMetricDot) d = -s;
+                else d = 1.0f - s / (sqrtf(as) * sqrtf(bs));
+                out[(uint64_t)gm * ostride + gn] = d;
+            }
+        }
+}
+
+// Bound on |d~ - d| (d = the exact-order f32 distance) for one query against any node of the
+// level: any-order f32 dot products of length D are within gamma_D * sum|x_i y_i| of the true
+// value, the exact-order L2 within gamma_(D/16+8) of it, centring adds u-relative component
+// errors; collected conservatively as (2.5 D + 64) * 2^-24 times
+//   L2: |q'|^2 + max|c'|^2      DOT: |q| max|c|      COSINE: 1.
+__device__ __forceinline__ float route_error_bound(uint32_t metric, uint32_t dim, float qsq, float max_csq) {
+    const float cu = (2.5f * (float)dim + 64.0f) * 5.9604645e-8f;
+    if (metric == kMetricL2) return cu * (qsq + max_csq);
+    if (metric == kMetricDot) return cu * sqrtf(qsq) * sqrtf(max_csq);
+    return cu;
+}
+
+// Per query: the kc smallest approximate distances of the level (positions in level order) and
+// the kc-th smallest value itself. One block per query.
+__global__ void __launch_bounds__(256)
+route_prefilter_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_t kc, uint32_t *cand_pos,
+                       uint32_t cstride, float *cand_max) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t misc[2];
+    __shared__ uint32_t wtmp[32];
+    const uint32_t q = blockIdx.x;
+    const float *fd = fdist + (uint64_t)q * fstride;
+    uint32_t budget;
+    const uint32_t T = block_radix_select(n, kc, [&](uint32_t i) { return f32_key(fd[i]); }, hist, misc, budget);
+    uint32_t *cp = cand_pos + (uint64_t)q * cstride;
+    ordered_threshold_compact(
+        n, T, budget, [&](uint32_t i) { return f32_key(fd[i]); },
+        [&](uint32_t i, uint32_t, uint32_t rank) { if (rank < cstride) cp[rank] = i; }, wtmp);
+    if (threadIdx.x == 0) cand_max[q] = f32_from_key(T);
+}
+
+// Exact distance(query, centroid, metric) of the prefiltered nodes (levels on this path hold more
+// than 100 nodes, so search() uses distance() for them, hierarchical.rs:355-365).
+// grid = (ceil(kc/64), nq), block 256: one 4-lane group per (query, candidate).
+__global__ void __launch_bounds__(256)
+route_refine_kernel(IndexDev ix, const float *queries, const uint32_t *level_nodes, const uint32_t *cand_pos,
+                    uint32_t cstride, uint32_t kc, float *cand_dist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *qs = reinterpret_cast<float *>(smem);
+    const uint32_t q = blockIdx.y, D = ix.dim;
+    const float *qg = queries + (uint64_t)q * D;
+    for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) qs[i] = qg[i];
+    __syncthreads();
+    const uint32_t j = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    const bool act = j < kc;
+    const uint32_t node = level_nodes[cand_pos[(uint64_t)q * cstride + (act ? j : 0)]];
+    float d = distance_group4(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, (D & 3) == 0);
+    if (act && sub == 0) cand_dist[(uint64_t)q * cstride + j] = d;
+}
+
+inline size_t route_finish_lds_bytes(uint32_t kpad, uint32_t probes) {
+    return (size_t)kpad * 8 + 2 * ((size_t)probes + 1) * 4 + 16;
+}
+
+// Per query: sort the refined candidates by (exact distance, level position); the first `probes`
+// are the exact selection provided no unselected node can beat the probes-th one:
+//     cand_max - error_bound > exact distance of the probes-th      (or every node was a candidate).
+// Then expand as route_select_kernel does. Otherwise raise flag[q] for the exact path.
+// One block per query; dynamic LDS = route_finish_lds_bytes(next_pow2(kc), probes).
+__global__ void __launch_bounds__(256)
+route_finish_kernel(IndexDev ix, const uint32_t *level_nodes, uint32_t n, const uint32_t *cand_pos,
+                    const float *cand_dist, uint32_t cstride, uint32_t kc, const float *cand_max, const float *qsq,
+                    float max_csq, uint32_t probes, uint32_t *next_frontier, uint32_t fstride, uint32_t *next_fcount,
+                    uint32_t *leaves, uint32_t lstride, uint32_t *lcount, uint32_t *flag, uint32_t *fallbacks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t kpad = next_pow2(kc);
+    uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *cnt_leaf = reinterpret_cast<uint32_t *>(skeys + kpad);
+    uint32_t *cnt_child = cnt_leaf + probes + 1;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t i = tid; i < kpad; i += blockDim.x)
+        skeys[i] = i < kc ? (((uint64_t)f32_key(cand_dist[(uint64_t)q * cstride + i]) << 32) | cand_pos[(uint64_t)q * cstride + i])
+                          : ~0ull;
+    __syncthreads();
+    block_bitonic_sort_u64(skeys, kpad);
+    const float tau = f32_from_key((uint32_t)(skeys[probes - 1] >> 32));
+    const float e = route_error_bound(ix.metric, ix.dim, qsq[q], max_csq);
+    const bool ok = kc >= n || (cand_max[q] - e > tau);
+    if (!ok) {
+        if (tid == 0) {
+            flag[q] = 1;
+            atomicAdd(fallbacks, 1u);
+        }
+        return;
+    }
+    if (tid == 0) flag[q] = 0;
+    route_expand(ix, level_nodes, skeys, probes, cnt_leaf, cnt_child, next_frontier + (uint64_t)q * fstride, fstride,
+                 next_fcount + q, leaves + (uint64_t)q * lstride, lstride, lcount + q);
+}
+
+} // namespace cuddle
