@@ -102,6 +102,7 @@ struct Plan {
     uint32_t cstride = 0;   // candidate capacity per query (spill buffer)
     uint32_t sstride = 0;   // selection capacity per query
     uint32_t dist_cap = 0;  // candidates kept in LDS by the scan kernel
+    uint32_t tcap = 0;      // 64-vector tiles per query (scan kernel)
     size_t scan_lds = 0;
     // carved pointers
     uint64_t *qcodes = nullptr;
@@ -482,7 +483,8 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     pl.cstride = (uint32_t)align_up(std::max<uint64_t>(cbound, 8), 8);
     pl.sstride = (uint32_t)align_up(std::max<uint64_t>(std::min<uint64_t>(pl.rerank_k, cbound), 4), 4);
     pl.dist_cap = std::min(pl.cstride, kLdsDistCap);
-    pl.scan_lds = scan_lds_bytes(v.dim, v.words, pl.lstride, pl.dist_cap);
+    pl.tcap = (uint32_t)align_up((size_t)pl.lstride + pl.cstride / 64 + 1, 4);
+    pl.scan_lds = scan_lds_bytes(v.dim, v.words, pl.lstride, pl.tcap, pl.dist_cap);
     if (pl.scan_lds > 150 * 1024) return fail(CUDDLE_ERR_UNSUPPORTED, "leaf list of %u slots does not fit the scan kernel's LDS", pl.lstride);
     // carve
     size_t off = 0;
@@ -614,7 +616,7 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
     const IndexDev &v = ix->dev;
     if (v.code_kind != CUDDLE_CODE_BINARY) return fail(CUDDLE_ERR_UNSUPPORTED, "RaBitQ scan is not built yet");
     hipLaunchKernelGGL(scan_select_hamming_kernel, dim3(nq), dim3(kScanThreads), pl.scan_lds, s, v, pl.qcodes, pl.leaves,
-                       pl.lstride, pl.lcount, pl.lstride, pl.rerank_k, pl.dist_cap, pl.gdist, pl.cstride, pl.sel_pos,
+                       pl.lstride, pl.lcount, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, pl.gdist, pl.cstride, pl.sel_pos,
                        pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count);
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
@@ -944,7 +946,7 @@ extern "C" cuddle_status cuddle_scan_batch(cuddle_index *idx, const float *queri
         HIP_TRY(hipMemcpy(io.q, queries + (uint64_t)q0 * dim, (size_t)qc * dim * 4, hipMemcpyHostToDevice));
         ST_TRY(upload_leaves(idx, pl, leaves, leaf_stride, leaf_count, q0, qc));
         ST_TRY(launch_quantize(idx, pl, io.q, qc, nullptr));
-        size_t lds = scan_lds_bytes(idx->dev.dim, idx->dev.words, pl.lstride, 0);
+        size_t lds = scan_lds_bytes(idx->dev.dim, idx->dev.words, pl.lstride, 0, 0);
         hipLaunchKernelGGL(scan_all_hamming_kernel, dim3(qc), dim3(256), lds, nullptr, idx->dev, pl.qcodes, pl.leaves,
                            pl.lstride, pl.lcount, pl.lstride, d_pos, d_key, cand_stride, pl.cand_count);
         HIP_TRY(hipGetLastError());

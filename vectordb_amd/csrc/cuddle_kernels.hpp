@@ -409,19 +409,26 @@ struct ScanLds {
     uint32_t *lbeg;     // [lcap]      first leaf-contiguous position of each leaf slot
     uint32_t *lcode;    // [lcap]      16-byte unit offset of the leaf's planar codes
     uint32_t *lscan;    // [lcap + 1]  exclusive prefix of leaf sizes = scan position of the leaf
+    uint32_t *ltile;    // [lcap + 1]  exclusive prefix of the leaves' 64-vector tile counts
+    uint32_t *tiles;    // [tcap]      (leaf slot << 12) | tile number inside the leaf
     uint32_t *wtmp;     // [32]
     uint32_t *misc;     // [8]
     uint64_t *qw;       // [words]
     uint16_t *dist;     // [dist_cap]
 };
 
-__device__ __forceinline__ ScanLds scan_lds_carve(unsigned char *smem, uint32_t dim, uint32_t words, uint32_t lcap) {
+__device__ __host__ __forceinline__ uint32_t scan_pad4(uint32_t v) { return (v + 3) & ~3u; }
+
+__device__ __forceinline__ ScanLds scan_lds_carve(unsigned char *smem, uint32_t dim, uint32_t words, uint32_t lcap,
+                                                  uint32_t tcap) {
     ScanLds s;
     uint32_t *p = reinterpret_cast<uint32_t *>(smem);
-    s.hist = p; p += ((dim + 2 + 3) & ~3u);
-    s.lbeg = p; p += ((lcap + 3) & ~3u);
-    s.lcode = p; p += ((lcap + 3) & ~3u);
-    s.lscan = p; p += ((lcap + 1 + 3) & ~3u);
+    s.hist = p; p += scan_pad4(dim + 2);
+    s.lbeg = p; p += scan_pad4(lcap);
+    s.lcode = p; p += scan_pad4(lcap);
+    s.lscan = p; p += scan_pad4(lcap + 1);
+    s.ltile = p; p += scan_pad4(lcap + 1);
+    s.tiles = p; p += scan_pad4(tcap);
     s.wtmp = p; p += 32;
     s.misc = p; p += 8;
     s.qw = reinterpret_cast<uint64_t *>(p); p += 2 * ((words + 1) & ~1u);
@@ -429,26 +436,38 @@ __device__ __forceinline__ ScanLds scan_lds_carve(unsigned char *smem, uint32_t 
     return s;
 }
 
-inline size_t scan_lds_bytes(uint32_t dim, uint32_t words, uint32_t lcap, uint32_t dist_cap) {
-    size_t u32s = ((dim + 2 + 3) & ~3u) + 2 * (size_t)((lcap + 3) & ~3u) + ((lcap + 1 + 3) & ~3u) + 32 + 8 +
-                  2 * (size_t)((words + 1) & ~1u);
+inline size_t scan_lds_bytes(uint32_t dim, uint32_t words, uint32_t lcap, uint32_t tcap, uint32_t dist_cap) {
+    size_t u32s = scan_pad4(dim + 2) + 2 * (size_t)scan_pad4(lcap) + 2 * (size_t)scan_pad4(lcap + 1) + scan_pad4(tcap) + 32 +
+                  8 + 2 * (size_t)((words + 1) & ~1u);
     return u32s * 4 + (size_t)dist_cap * 2;
 }
 
-// Loads the query's leaf descriptors into LDS and prefix-sums the leaf sizes. Returns the number
-// of candidates C. All threads call.
+// Loads the query's leaf descriptors into LDS, prefix-sums the leaf sizes (scan positions) and
+// cuts every leaf into tiles of 64 vectors (the unit one wave processes per step). Returns the
+// number of candidates C; *ntiles receives the tile count (capped at tcap). All threads call.
 __device__ __forceinline__ uint32_t scan_load_leaves(const IndexDev &ix, const ScanLds &s, const uint32_t *lv,
-                                                     uint32_t nl) {
+                                                     uint32_t nl, uint32_t tcap, uint32_t *ntiles) {
     for (uint32_t t = threadIdx.x; t < nl; t += blockDim.x) {
         uint32_t node = lv[t];
         uint32_t b = ix.vec_off[node], e = ix.vec_off[node + 1];
         s.lbeg[t] = b;
         s.lscan[t] = e - b;
+        s.ltile[t] = (e - b + 63) >> 6;
         s.lcode[t] = ix.code_off[node];
     }
     __syncthreads();
     wave0_exclusive_scan_lds(s.lscan, nl);
     __syncthreads();
+    wave0_exclusive_scan_lds(s.ltile, nl);
+    __syncthreads();
+    if (tcap) {
+        for (uint32_t t = threadIdx.x; t < nl; t += blockDim.x) {
+            const uint32_t tb = s.ltile[t], te = s.ltile[t + 1];
+            for (uint32_t c = tb; c < te && c < tcap; ++c) s.tiles[c] = (t << 12) | (c - tb);
+        }
+        __syncthreads();
+    }
+    if (ntiles) *ntiles = min(s.ltile[nl], tcap);
     return s.lscan[nl];
 }
 
@@ -462,29 +481,75 @@ __device__ __forceinline__ uint32_t scan_slot_of(const uint32_t *lscan, uint32_t
     return lo;
 }
 
-// One block per query. Phase 1 streams the planar codes of every reached leaf (one wave per leaf
-// at a time, lane = vector), XOR + popcount against the query code, and keeps each candidate's
+// Phase 1 of the scan for codes of 2*PAIRS (+1 if TAIL) words: each wave takes U tiles at a time
+// and issues all of their 128-bit loads (U * PAIRS per lane, every one a fully coalesced
+// wave-wide read of consecutive 16-byte slots) before the first XOR/popcount, so that one wave
+// keeps U * PAIRS KiB in flight.
+template <int PAIRS, bool TAIL, int U>
+__device__ __forceinline__ void scan_tiles(const IndexDev &ix, const ScanLds &s, uint32_t ntiles, bool use_lds,
+                                           uint16_t *gd) {
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (uint32_t t0 = w * U; t0 < ntiles; t0 += nw * U) {
+        uint4 c[U][PAIRS > 0 ? PAIRS : 1];
+        uint2 ct[U];
+        uint32_t pos[U];
+        bool act[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t t = t0 + u;
+            const uint32_t tile = s.tiles[t < ntiles ? t : t0];
+            const uint32_t sl = tile >> 12, i = ((tile & 4095u) << 6) + lane;
+            const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base;
+            act[u] = t < ntiles && i < n;
+            pos[u] = base + i;
+            const uint4 *planes = ix.codes + s.lcode[sl];
+#pragma unroll
+            for (int p = 0; p < PAIRS; ++p) c[u][p] = act[u] ? planes[(uint64_t)p * n + i] : make_uint4(0, 0, 0, 0);
+            if (TAIL) {
+                const uint2 *tail = reinterpret_cast<const uint2 *>(planes + (uint64_t)PAIRS * n);
+                ct[u] = act[u] ? tail[i] : make_uint2(0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t h = 0;
+#pragma unroll
+            for (int p = 0; p < PAIRS; ++p) {
+                const uint64_t a = ((uint64_t)c[u][p].y << 32) | c[u][p].x, b = ((uint64_t)c[u][p].w << 32) | c[u][p].z;
+                h += __popcll(a ^ s.qw[2 * p]) + __popcll(b ^ s.qw[2 * p + 1]);
+            }
+            if (TAIL) h += __popcll((((uint64_t)ct[u].y << 32) | ct[u].x) ^ s.qw[2 * PAIRS]);
+            if (act[u]) {
+                if (use_lds) s.dist[pos[u]] = (uint16_t)h; else gd[pos[u]] = (uint16_t)h;
+                atomicAdd(&s.hist[h], 1u);
+            }
+        }
+    }
+}
+
+// One block per query. Phase 1 streams the planar codes of every reached leaf (tiles of 64
+// vectors, lane = vector), XOR + popcount against the query code, and keeps each candidate's
 // Hamming distance as u16 (LDS when the query's candidates fit in dist_cap, else the global
 // spill buffer) while building a (dim+1)-bin histogram. Phase 2 turns the histogram into the
 // selection threshold: T = smallest h with #(<= h) >= rerank_k, budget = rerank_k - #(< T).
 // Phase 3 emits, in scan order, every candidate with h < T and the first `budget` with h == T:
 // the first rerank_k elements of the reference's stable sort_by_key (hierarchical.rs:646-648,
 // :930-932), i.e. a legal result of select_nth_unstable_by (:651), listed in scan order.
-// sel_pos / sel_key: [nq][sel_stride]; gdist: [nq][gdist_stride] u16 spill (may be null when
-// dist_cap always suffices).
+// sel_pos / sel_key: [nq][sel_stride]; gdist: [nq][gdist_stride] u16 spill.
 __global__ void __launch_bounds__(512)
 scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *leaves, uint32_t lstride,
-                           const uint32_t *lcount, uint32_t lcap, uint32_t rerank_k, uint32_t dist_cap,
+                           const uint32_t *lcount, uint32_t lcap, uint32_t tcap, uint32_t rerank_k, uint32_t dist_cap,
                            uint16_t *gdist, uint32_t gdist_stride, uint32_t *sel_pos, uint32_t *sel_key,
                            uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const uint32_t D = ix.dim, W = ix.words;
-    ScanLds s = scan_lds_carve(smem, D, W, lcap);
+    ScanLds s = scan_lds_carve(smem, D, W, lcap, tcap);
     const uint32_t nl = min(lcount[q], lcap);
     for (uint32_t i = tid; i < D + 2; i += blockDim.x) s.hist[i] = 0;
     for (uint32_t i = tid; i < W; i += blockDim.x) s.qw[i] = qcodes[(uint64_t)q * W + i];
-    const uint32_t C = scan_load_leaves(ix, s, leaves + (uint64_t)q * lstride, nl);
+    uint32_t ntiles = 0;
+    const uint32_t C = scan_load_leaves(ix, s, leaves + (uint64_t)q * lstride, nl, tcap, &ntiles);
     if (tid == 0) cand_count[q] = C;
     if (C == 0) {
         if (tid == 0) sel_count[q] = 0;
@@ -493,13 +558,23 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
     const bool use_lds = C <= dist_cap;
     uint16_t *gd = gdist + (uint64_t)q * gdist_stride;
     // phase 1
-    for (uint32_t sl = w; sl < nl; sl += nw) {
-        const uint32_t n = s.lscan[sl + 1] - s.lscan[sl], base = s.lscan[sl];
-        const uint4 *planes = ix.codes + s.lcode[sl];
-        for (uint32_t i = lane; i < n; i += 64) {
-            uint32_t h = leaf_hamming(planes, n, i, s.qw, W);
-            if (use_lds) s.dist[base + i] = (uint16_t)h; else gd[base + i] = (uint16_t)h;
-            atomicAdd(&s.hist[h], 1u);
+    switch (W) {
+    case 2: scan_tiles<1, false, 8>(ix, s, ntiles, use_lds, gd); break;    // 128-d
+    case 4: scan_tiles<2, false, 8>(ix, s, ntiles, use_lds, gd); break;    // 256-d
+    case 8: scan_tiles<4, false, 4>(ix, s, ntiles, use_lds, gd); break;    // 512-d
+    case 12: scan_tiles<6, false, 2>(ix, s, ntiles, use_lds, gd); break;   // 768-d
+    case 15: scan_tiles<7, true, 2>(ix, s, ntiles, use_lds, gd); break;    // 960-d
+    case 16: scan_tiles<8, false, 2>(ix, s, ntiles, use_lds, gd); break;   // 1024-d
+    case 24: scan_tiles<12, false, 1>(ix, s, ntiles, use_lds, gd); break;  // 1536-d
+    default:
+        for (uint32_t t = w; t < ntiles; t += nw) {
+            const uint32_t tile = s.tiles[t], sl = tile >> 12, i = ((tile & 4095u) << 6) + lane;
+            const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base;
+            if (i < n) {
+                uint32_t h = leaf_hamming(ix.codes + s.lcode[sl], n, i, s.qw, W);
+                if (use_lds) s.dist[base + i] = (uint16_t)h; else gd[base + i] = (uint16_t)h;
+                atomicAdd(&s.hist[h], 1u);
+            }
         }
     }
     __syncthreads();
@@ -557,10 +632,10 @@ scan_all_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *lea
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const uint32_t W = ix.words;
-    ScanLds s = scan_lds_carve(smem, ix.dim, W, lcap);
+    ScanLds s = scan_lds_carve(smem, ix.dim, W, lcap, 0);
     const uint32_t nl = min(lcount[q], lcap);
     for (uint32_t i = tid; i < W; i += blockDim.x) s.qw[i] = qcodes[(uint64_t)q * W + i];
-    const uint32_t C = scan_load_leaves(ix, s, leaves + (uint64_t)q * lstride, nl);
+    const uint32_t C = scan_load_leaves(ix, s, leaves + (uint64_t)q * lstride, nl, 0, nullptr);
     if (tid == 0) cand_count[q] = C;
     for (uint32_t sl = w; sl < nl; sl += nw) {
         const uint32_t n = s.lscan[sl + 1] - s.lscan[sl], base = s.lscan[sl];

@@ -41,14 +41,21 @@ __device__ __forceinline__ uint32_t block_radix_select(uint32_t n, uint32_t want
             if ((kv & himask) == prefix) atomicAdd(&hist[(kv >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t cum = 0, b = 0;
-            for (; b < 255; ++b) {
-                if (cum + hist[b] >= want) break;
-                cum += hist[b];
+        if (threadIdx.x < 64) { // wave 0: prefix-sum the 256 buckets, 4 per lane
+            const uint32_t l = threadIdx.x;
+            const uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+            const uint32_t s4 = h0 + h1 + h2 + h3;
+            const uint32_t incl = wave_inclusive_sum(s4);
+            const uint64_t hit = __ballot(incl >= want);
+            const uint32_t first = hit ? (uint32_t)__ffsll((unsigned long long)hit) - 1 : 63u;
+            if (l == first) {
+                uint32_t cum = incl - s4, b = 4 * l;
+                if (cum + h0 < want) { cum += h0; ++b;
+                    if (cum + h1 < want) { cum += h1; ++b;
+                        if (cum + h2 < want) { cum += h2; ++b; } } }
+                misc[0] = prefix | (b << shift);
+                misc[1] = want - cum;
             }
-            misc[0] = prefix | (b << shift);
-            misc[1] = want - cum;
         }
         __syncthreads();
         prefix = misc[0];
