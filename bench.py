@@ -289,6 +289,7 @@ def main():
         "candidates_per_query": stats["vectors_scanned"] / nq,
         "leaves_per_query": stats["leaves_searched"] / nq,
         "reranked_per_query": stats["vectors_reranked"] / nq,
+        "route_fallbacks_per_batch": stats["route_fallbacks"],
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

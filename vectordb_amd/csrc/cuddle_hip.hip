@@ -121,8 +121,8 @@ struct Plan {
 
 // Per-level operand of the MFMA routing contraction (see level_table_kernel).
 struct LevelGemm {
-    uint32_t n = 0;            // 0: not built for this level
-    uint32_t *nodes = nullptr; // [n] node ids, breadth-first order
+    uint32_t n = 0;            // 0: contraction operands not built for this level
+    uint32_t *nodes = nullptr; // [level width] node ids, breadth-first order (every level has it)
     float *table = nullptr;    // [n][dim] centroid - mu
     float *sqn = nullptr;      // [n]
     float *mu = nullptr;       // [dim]
@@ -138,6 +138,7 @@ struct cuddle_index {
     float threshold = 0.f; // BinaryQuantizer::threshold
     std::vector<uint32_t> level_width;
     std::vector<LevelGemm> lvl;
+    std::vector<uint32_t> level_leaves; // leaf nodes per level
     DevBuf ws;       // per-chunk work space (Plan)
     DevBuf io;       // staging for the host entry points
     DevStats *d_stats = nullptr;
@@ -197,13 +198,23 @@ static cuddle_status dev_alloc(cuddle_index *ix, size_t count, T **dst) {
 namespace cuddle {
 __global__ void stats_accum_kernel(const uint32_t *lcount, const uint32_t *cand_count, const uint32_t *sel_count,
                                    uint32_t nq, DevStats *st) {
-    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    atomicAdd(&st->leaves, (unsigned long long)lcount[q]);
-    atomicAdd(&st->scanned, (unsigned long long)cand_count[q]);
-    atomicAdd(&st->reranked, (unsigned long long)sel_count[q]);
-    atomicMax(&st->max_cand, cand_count[q]);
-    atomicMax(&st->max_leaves, lcount[q]);
+    unsigned long long l = 0, c = 0, r = 0;
+    uint32_t mc = 0, ml = 0;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        l += lcount[q]; c += cand_count[q]; r += sel_count[q];
+        mc = max(mc, cand_count[q]); ml = max(ml, lcount[q]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        l += __shfl_xor(l, o, 64); c += __shfl_xor(c, o, 64); r += __shfl_xor(r, o, 64);
+        mc = max(mc, (uint32_t)__shfl_xor((int)mc, o, 64)); ml = max(ml, (uint32_t)__shfl_xor((int)ml, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&st->leaves, l);
+        atomicAdd(&st->scanned, c);
+        atomicAdd(&st->reranked, r);
+        atomicMax(&st->max_cand, mc);
+        atomicMax(&st->max_leaves, ml);
+    }
 }
 // Sum of squares of each centroid as a k-ordered fused-multiply-add chain (the form the f32 MFMA
 // contraction produces), used by the MFMA routing filter.
@@ -341,6 +352,12 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
 
     // operands of the MFMA routing contraction, for every level wide enough to use it
     ix->lvl.assign(n_levels, LevelGemm());
+    ix->level_leaves.assign(n_levels, 0);
+    for (uint32_t l = 0; l < n_levels; ++l) {
+        for (uint32_t v2 : level_nodes[l])
+            if (d->child_offsets[v2 + 1] == d->child_offsets[v2]) ix->level_leaves[l]++;
+        ST_TRY(upload(ix, level_nodes[l].data(), level_nodes[l].size(), &ix->lvl[l].nodes));
+    }
     if (D % 4 == 0) {
         for (uint32_t l = 0; l < n_levels; ++l) {
             const std::vector<uint32_t> &nodes = level_nodes[l];
@@ -353,7 +370,6 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
                     for (uint32_t i = 0; i < D; ++i) acc[i] += d->centroids[(size_t)v2 * D + i];
                 for (uint32_t i = 0; i < D; ++i) mu[i] = (float)(acc[i] / (double)nodes.size());
             }
-            ST_TRY(upload(ix, nodes.data(), nodes.size(), &g.nodes));
             ST_TRY(upload(ix, mu.data(), (size_t)D, &g.mu));
             ST_TRY(dev_alloc(ix, nodes.size() * (size_t)D, &g.table));
             ST_TRY(dev_alloc(ix, nodes.size(), &g.sqn));
@@ -449,6 +465,13 @@ extern "C" uint64_t cuddle_index_device_bytes(const cuddle_index *idx) {
 // ---------------------------------------------------------------------------------------------
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Extra candidates the MFMA routing filter keeps beyond `probes` (they absorb the rounding error of
+// the norm-expansion distances; too few only costs exact-path fallbacks, never correctness).
+static uint32_t route_margin(uint32_t probes) {
+    if (const char *e = getenv("CUDDLE_ROUTE_MARGIN")) return (uint32_t)std::max(0, atoi(e));
+    return std::max<uint32_t>(24, probes / 8);
+}
+
 // lstride_min: lower bound for the leaf-list capacity (stage entry points pass their own lists).
 static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32_t probes, uint64_t rerank_k64,
                                uint32_t lstride_min, Plan &pl) {
@@ -498,7 +521,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     size_t o_gd = carve(qc * (size_t)pl.cstride * 4); // u16 Hamming or f32 estimates
     size_t o_sp = carve(qc * pl.sstride * 4), o_sk = carve(qc * pl.sstride * 4), o_sd = carve(qc * pl.sstride * 4);
     size_t o_sc = carve(qc * 4), o_cc = carve(qc * 4);
-    pl.kc_cap = (uint32_t)align_up((size_t)pl.probes + std::max<uint32_t>(64, pl.probes / 4), 64);
+    pl.kc_cap = (uint32_t)align_up((size_t)pl.probes + route_margin(pl.probes), 32);
     size_t o_qcent = carve(qc * v.dim * 4), o_qsq = carve(qc * 4);
     size_t o_rcp = carve(qc * pl.kc_cap * 4), o_rcd = carve(qc * pl.kc_cap * 4), o_rcm = carve(qc * 4), o_rfl = carve(qc * 4);
     pl.bytes = off;
@@ -568,17 +591,28 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                                   hipStream_t s) {
     const IndexDev &v = ix->dev;
     const uint32_t stats = (flags & CUDDLE_SEARCH_STATS_VARIANT) ? 1u : 0u;
+    // `shared`: every query's frontier at this level is the level's full node list, in
+    // breadth-first order (true while all earlier levels kept all their nodes, search() only:
+    // search_with_stats re-orders every level).
+    bool shared = !stats;
     hipLaunchKernelGGL(route_init_kernel, dim3((v.n_roots + 255) / 256, nq), dim3(256), 0, s, v.roots, v.n_roots,
-                       pl.frontier[0], pl.fstride, pl.fcount[0], pl.lcount, nq);
+                       pl.frontier[0], pl.fstride, pl.fcount[0], pl.lcount, nq, shared ? 0u : 1u);
     int cur = 0;
     uint64_t fb = v.n_roots;
-    bool shared = !stats;
     for (uint32_t l = 0; l < ix->n_levels; ++l) {
         fb = std::min<uint64_t>(fb, ix->level_width[l]);
         const uint32_t bound = (uint32_t)std::max<uint64_t>(fb, 1);
         const bool keep_all = !stats && bound <= pl.probes;
         const uint32_t scap = std::min(kSortCap, host_next_pow2(bound));
         const LevelGemm &g = ix->lvl[l];
+        const uint32_t *sfr = shared ? g.nodes : nullptr;
+        const uint32_t sn = shared ? ix->level_width[l] : 0;
+        const bool next_shared = shared && keep_all;
+        if (shared && keep_all && ix->level_leaves[l] == 0) {
+            // every node of the level is kept and none is a leaf: nothing to compute or record
+            fb = std::min<uint64_t>(fb, pl.probes) * std::max<uint32_t>(ix->max_children, 1);
+            continue;
+        }
         const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound;
         const uint32_t *only = nullptr;
         if (use_gemm) {
@@ -599,12 +633,13 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         }
         if (!keep_all)
             hipLaunchKernelGGL(route_dist_kernel, dim3((bound + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
-                               pl.frontier[cur], pl.fstride, pl.fcount[cur], pl.fdist, pl.probes, stats, only);
+                               pl.frontier[cur], pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, only);
         hipLaunchKernelGGL(route_select_kernel, dim3(nq), dim3(256), route_select_lds_bytes(scap), s, v, pl.frontier[cur],
-                           pl.fstride, pl.fcount[cur], pl.fdist, pl.probes, stats, scap, pl.frontier[cur ^ 1],
-                           pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount, only);
+                           pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, scap,
+                           next_shared ? nullptr : pl.frontier[cur ^ 1], pl.fcount[cur ^ 1], pl.leaves, pl.lstride,
+                           pl.lcount, only);
         cur ^= 1;
-        shared = shared && keep_all;
+        shared = next_shared;
         fb = std::min<uint64_t>(fb, pl.probes) * std::max<uint32_t>(ix->max_children, 1);
     }
     HIP_TRY(hipGetLastError());
@@ -636,7 +671,7 @@ static cuddle_status launch_topk(cuddle_index *ix, const Plan &pl, uint32_t nq, 
     size_t lds = (size_t)host_next_pow2(pl.sstride) * 8;
     hipLaunchKernelGGL(topk_kernel, dim3(nq), dim3(256), lds, s, v, pl.sel_pos, pl.sel_key, pl.sel_dist, pl.sstride,
                        pl.sel_count, pl.k, v.code_kind == CUDDLE_CODE_RABITQ ? 1u : 0u, d_ids, d_dist, d_count);
-    hipLaunchKernelGGL(stats_accum_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, pl.lcount, pl.cand_count,
+    hipLaunchKernelGGL(stats_accum_kernel, dim3(std::min<uint32_t>((nq + 255) / 256, 8)), dim3(256), 0, s, pl.lcount, pl.cand_count,
                        pl.sel_count, nq, ix->d_stats);
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;

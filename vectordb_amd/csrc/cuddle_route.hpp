@@ -68,8 +68,9 @@ __device__ __forceinline__ uint32_t block_radix_select(uint32_t n, uint32_t want
 
 // Split the chosen nodes into leaves and internal nodes (hierarchical.rs:411-413), append the
 // leaves to the query's leaf list (:416) and write the children of the internal nodes, in order,
-// as the next frontier (:419-422). skeys[i] (low 32 bits) = position in `fr` of the i-th chosen
-// node. cnt_leaf / cnt_child: nsel + 1 u32 of LDS each. All threads of the block call.
+// as the next frontier (:419-422; skipped when nf is null: the next level's frontier is then the
+// level's full node list, known without writing it per query). skeys[i] (low 32 bits) = position
+// in `fr` of the i-th chosen node. cnt_leaf / cnt_child: nsel + 1 u32 of LDS each. All threads call.
 __device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t *fr, const uint64_t *skeys,
                                              uint32_t nsel, uint32_t *cnt_leaf, uint32_t *cnt_child, uint32_t *nf,
                                              uint32_t fstride, uint32_t *next_fcount_q, uint32_t *lv, uint32_t lstride,
@@ -97,7 +98,7 @@ __device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t 
                 uint32_t slot = lbase + cnt_leaf[i];
                 if (slot < lstride) lv[slot] = node;
             }
-        } else {
+        } else if (nf) {
             uint32_t ob = cnt_child[i];
             for (uint32_t c = lane; c < ce - cb; c += 64)
                 if (ob + c < fstride) nf[ob + c] = ix.children[cb + c];
@@ -106,17 +107,18 @@ __device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t 
     __syncthreads();
     if (tid == 0) {
         *lcount_q = min(lbase + cnt_leaf[nsel], lstride);
-        *next_fcount_q = min(cnt_child[nsel], fstride);
+        if (nf) *next_fcount_q = min(cnt_child[nsel], fstride);
     }
 }
 
-// Level start: frontier = root_ids for every query (hierarchical.rs:346).
+// Level start: frontier = root_ids for every query (hierarchical.rs:346). write_roots = 0 when the
+// first level is evaluated from the shared root list.
 __global__ void route_init_kernel(const uint32_t *roots, uint32_t n_roots, uint32_t *frontier, uint32_t fstride,
-                                  uint32_t *fcount, uint32_t *lcount, uint32_t nq) {
+                                  uint32_t *fcount, uint32_t *lcount, uint32_t nq, uint32_t write_roots) {
     uint32_t q = blockIdx.y;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
-    if (i < n_roots) frontier[(uint64_t)q * fstride + i] = roots[i];
+    if (write_roots && i < n_roots) frontier[(uint64_t)q * fstride + i] = roots[i];
     if (i == 0) {
         fcount[q] = n_roots;
         lcount[q] = 0;
@@ -132,17 +134,18 @@ __global__ void route_init_kernel(const uint32_t *roots, uint32_t n_roots, uint3
 // 4 <= n <= 100: l2_squared_batch, i.e. batch4 arithmetic for the first 4*floor(n/4) nodes and
 // l2_squared for the rest, whatever the metric. stats_variant: always distance(metric) (:868-886).
 // Nothing is computed for a query whose nodes are all kept (n <= probes, :395-397).
-// only_flag != null: only queries with only_flag[q] != 0 are processed.
+// only_flag != null: only queries with only_flag[q] != 0 are processed. shared_fr != null: every
+// query's frontier is the list shared_fr[0..shared_n) (frontier / fcount are not read).
 // grid = (ceil(bound/64), nq), block = 256: one 4-lane group per (query, node).
 __global__ void __launch_bounds__(256)
 route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, uint32_t fstride,
-                  const uint32_t *fcount, float *fdist, uint32_t probes, uint32_t stats_variant,
-                  const uint32_t *only_flag) {
+                  const uint32_t *fcount, const uint32_t *shared_fr, uint32_t shared_n, float *fdist, uint32_t probes,
+                  uint32_t stats_variant, const uint32_t *only_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);
     const uint32_t q = blockIdx.y;
     if (only_flag && !only_flag[q]) return;
-    const uint32_t n = fcount[q];
+    const uint32_t n = shared_fr ? shared_n : fcount[q];
     if (!stats_variant && n <= probes) return;
     const uint32_t D = ix.dim;
     const bool small = !stats_variant && n >= 4 && n <= 100;
@@ -150,7 +153,7 @@ route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, u
     const float *qg = queries + (uint64_t)q * D;
     for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) qs[i] = qg[i];
     __syncthreads();
-    const uint32_t *fr = frontier + (uint64_t)q * fstride;
+    const uint32_t *fr = shared_fr ? shared_fr : frontier + (uint64_t)q * fstride;
     float *fd = fdist + (uint64_t)q * fstride;
     if (small) {
         uint32_t j = threadIdx.x;
@@ -178,11 +181,13 @@ inline size_t route_select_lds_bytes(uint32_t scap) {
 //   otherwise: the min(n, probes) smallest by (distance, frontier position), in that order.
 // scap (a power of two <= kSortCap) bounds the sorted set: min(n, probes) <= scap whenever n > scap
 // is possible. One block per query; dynamic LDS = route_select_lds_bytes(scap).
+// shared_fr != null: every query's frontier is shared_fr[0..shared_n). next_frontier == null: the
+// children are not written (see route_expand).
 __global__ void __launch_bounds__(256)
 route_select_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, const uint32_t *fcount,
-                    const float *fdist, uint32_t probes, uint32_t stats_variant, uint32_t scap,
-                    uint32_t *next_frontier, uint32_t *next_fcount, uint32_t *leaves, uint32_t lstride,
-                    uint32_t *lcount, const uint32_t *only_flag) {
+                    const uint32_t *shared_fr, uint32_t shared_n, const float *fdist, uint32_t probes,
+                    uint32_t stats_variant, uint32_t scap, uint32_t *next_frontier, uint32_t *next_fcount,
+                    uint32_t *leaves, uint32_t lstride, uint32_t *lcount, const uint32_t *only_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);                 // [scap]
     uint32_t *hist = reinterpret_cast<uint32_t *>(skeys + scap);         // [256]
@@ -192,13 +197,13 @@ route_select_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, con
     uint32_t *cnt_child = cnt_leaf + scap + 1;                           // [scap + 1]
     const uint32_t q = blockIdx.x;
     if (only_flag && !only_flag[q]) return;
-    const uint32_t n = fcount[q];
+    const uint32_t n = shared_fr ? shared_n : fcount[q];
     const uint32_t tid = threadIdx.x;
     if (n == 0) {
-        if (tid == 0) next_fcount[q] = 0;
+        if (tid == 0 && next_frontier) next_fcount[q] = 0;
         return;
     }
-    const uint32_t *fr = frontier + (uint64_t)q * fstride;
+    const uint32_t *fr = shared_fr ? shared_fr : frontier + (uint64_t)q * fstride;
     const float *fd = fdist + (uint64_t)q * fstride;
     uint32_t nsel;
     const bool keep_all = !stats_variant && n <= probes;
@@ -226,8 +231,9 @@ route_select_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, con
         }
         block_bitonic_sort_u64(skeys, npad);
     }
-    route_expand(ix, fr, skeys, nsel, cnt_leaf, cnt_child, next_frontier + (uint64_t)q * fstride, fstride,
-                 next_fcount + q, leaves + (uint64_t)q * lstride, lstride, lcount + q);
+    route_expand(ix, fr, skeys, nsel, cnt_leaf, cnt_child,
+                 next_frontier ? next_frontier + (uint64_t)q * fstride : nullptr, fstride, next_fcount + q,
+                 leaves + (uint64_t)q * lstride, lstride, lcount + q);
 }
 
 // ---------------------------------------------------------------------------------------------
