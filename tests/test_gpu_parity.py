@@ -101,3 +101,30 @@ def test_mfma_routing_is_exact(gpu, metric):
     ids, dist, cnt, st = dev.search_batch(q, 10, probes, 5, want_stats=True)
     assert st["route_fallbacks"] <= q.shape[0] // 10, st
     _compare_full(fi, dev, q[:40], 10, probes, 5)
+
+
+@pytest.mark.parametrize("metric,d", [("l2", 64), ("cosine", 96), ("dot", 40)])
+def test_rabitq_search_matches_oracle(gpu, metric, d):
+    """RaBitQ phase 1: rotation, estimates, f32 selection, rerank, top-k — all bit-exact."""
+    orc = _oracle()
+    x, fi = small_index(n=6000, d=d, n_clusters=40, branching=10, leaf=30, metric=metric, code_kind="rabitq")
+    dev = DeviceIndex(fi, gpu)
+    oi = orc.OracleIndex(fi)
+    q = queries_like(x, 48, 17)
+    q[5] = 0.0  # zero query: estimate = norm^2 (rabitq.rs:408-413); cosine distance would be NaN, so L2/dot only
+    if metric == "cosine":
+        q[5] = x[5]
+    _compare_full(fi, dev, q, 10, 5, 10)
+    _compare_full(fi, dev, q, 100, 8, 10)
+    _compare_full(fi, dev, q, 10, 5, 10, _ffi.SEARCH_STATS_VARIANT)
+    leaves, lcnt = dev.route_batch(q, 5)
+    pos, key, ccnt = dev.scan_batch(q, leaves, lcnt)
+    ids, dist, cnt, spos, skey, sdist, scnt = dev.search_leaves_batch(q, leaves, lcnt, 10, 10)
+    for i in range(q.shape[0]):
+        t = oi.search(q[i], 10, 5, 10, trace=True)
+        assert t["rc"] == 0
+        assert np.array_equal(pos[i, :ccnt[i]], t["cand_pos"])
+        assert np.array_equal(key[i, :ccnt[i]], t["cand_key"]), i  # f32 bit patterns of the estimates
+        assert np.array_equal(spos[i, :scnt[i]], t["sel_pos"])
+        assert np.array_equal(skey[i, :scnt[i]], t["sel_key"])
+        assert np.array_equal(sdist[i, :scnt[i]].view(np.uint32), t["sel_dist"].view(np.uint32))

@@ -17,6 +17,7 @@
 
 #include "cuddle_kernels.hpp"
 #include "cuddle_route.hpp"
+#include "cuddle_rabitq.hpp"
 
 using namespace cuddle;
 
@@ -408,8 +409,11 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
         }
         v.codes = reinterpret_cast<const uint4 *>(planar);
     } else {
-        float *rot, *norm, *ipoo; uint32_t *rc = nullptr, *raw = nullptr;
+        float *rot, *rot_tr = nullptr, *norm, *ipoo; uint32_t *rc = nullptr, *raw = nullptr;
         st = upload(ix, d->rabitq_rot_t, (size_t)D * D, &rot);
+        if (st == CUDDLE_OK) st = dev_alloc(ix, (size_t)D * D, &rot_tr);
+        if (st == CUDDLE_OK)
+            hipLaunchKernelGGL(transpose_square_kernel, dim3((D + 255) / 256, D), dim3(256), 0, 0, rot, rot_tr, D);
         if (st == CUDDLE_OK) st = upload(ix, d->rabitq_norm, (size_t)N, &norm);
         if (st == CUDDLE_OK) st = upload(ix, d->rabitq_ip_oo, (size_t)N, &ipoo);
         if (st == CUDDLE_OK) st = dev_alloc(ix, (size_t)N * W32, &rc);
@@ -426,7 +430,7 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
             (void)hipDeviceSynchronize();
             if (raw) (void)hipFree(raw);
         }
-        if (st == CUDDLE_OK) { v.rot_t = rot; v.rq_norm = norm; v.rq_ipoo = ipoo; v.rq_codes = rc; }
+        if (st == CUDDLE_OK) { v.rot_t = rot; v.rot = rot_tr; v.rq_norm = norm; v.rq_ipoo = ipoo; v.rq_codes = rc; }
     }
     if (d_pos_leaf) (void)hipFree(d_pos_leaf);
     if (st != CUDDLE_OK) return st;
@@ -440,6 +444,11 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     (void)hipFuncSetAttribute((const void *)scan_select_hamming_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_all_hamming_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)scan_select_rabitq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)scan_all_rabitq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)selection_sort_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError(); // attribute failures are not fatal: launches that need the space report them
     guard.p = nullptr;
     *out = ix;
     return CUDDLE_OK;
@@ -505,9 +514,14 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     uint64_t cbound = std::min<uint64_t>((uint64_t)pl.lstride * ix->max_leaf, v.n_vectors);
     pl.cstride = (uint32_t)align_up(std::max<uint64_t>(cbound, 8), 8);
     pl.sstride = (uint32_t)align_up(std::max<uint64_t>(std::min<uint64_t>(pl.rerank_k, cbound), 4), 4);
-    pl.dist_cap = std::min(pl.cstride, kLdsDistCap);
     pl.tcap = (uint32_t)align_up((size_t)pl.lstride + pl.cstride / 64 + 1, 4);
-    pl.scan_lds = scan_lds_bytes(v.dim, v.words, pl.lstride, pl.tcap, pl.dist_cap);
+    if (v.code_kind == CUDDLE_CODE_BINARY) {
+        pl.dist_cap = std::min(pl.cstride, kLdsDistCap);
+        pl.scan_lds = scan_lds_bytes(v.dim, v.words, pl.lstride, pl.tcap, pl.dist_cap);
+    } else {
+        pl.dist_cap = std::min(pl.cstride, kLdsDistCap / 2); // f32 estimates
+        pl.scan_lds = rabitq_scan_lds_bytes(v.dim, pl.lstride, pl.tcap, pl.dist_cap);
+    }
     if (pl.scan_lds > 150 * 1024) return fail(CUDDLE_ERR_UNSUPPORTED, "leaf list of %u slots does not fit the scan kernel's LDS", pl.lstride);
     // carve
     size_t off = 0;
@@ -577,7 +591,9 @@ static cuddle_status launch_quantize(cuddle_index *ix, const Plan &pl, const flo
         hipLaunchKernelGGL(binary_quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dq, (uint64_t)nq,
                            v.dim, v.words, ix->threshold, pl.qcodes);
     } else {
-        return fail(CUDDLE_ERR_UNSUPPORTED, "RaBitQ query preparation is not built yet");
+        float *rq = reinterpret_cast<float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
+        hipLaunchKernelGGL(rabitq_query_prep_kernel, dim3((nq + kPrepQ - 1) / kPrepQ), dim3(256), kPrepQ * v.dim * sizeof(float),
+                           s, dq, v.rot, nq, v.dim, rq, qn);
     }
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
@@ -649,7 +665,17 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
 // Scan + phase-1 selection for the leaf lists in pl.leaves / pl.lcount.
 static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32_t nq, hipStream_t s) {
     const IndexDev &v = ix->dev;
-    if (v.code_kind != CUDDLE_CODE_BINARY) return fail(CUDDLE_ERR_UNSUPPORTED, "RaBitQ scan is not built yet");
+    if (v.code_kind == CUDDLE_CODE_RABITQ) {
+        const float *rq = reinterpret_cast<const float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
+        hipLaunchKernelGGL(scan_select_rabitq_kernel, dim3(nq), dim3(kScanThreads), pl.scan_lds, s, v, rq, qn, pl.leaves,
+                           pl.lstride, pl.lcount, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap,
+                           reinterpret_cast<float *>(pl.gdist), pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count,
+                           pl.cand_count);
+        hipLaunchKernelGGL(selection_sort_f32_kernel, dim3(nq), dim3(256), (size_t)host_next_pow2(pl.sstride) * 16, s,
+                           pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count);
+        HIP_TRY(hipGetLastError());
+        return CUDDLE_OK;
+    }
     hipLaunchKernelGGL(scan_select_hamming_kernel, dim3(nq), dim3(kScanThreads), pl.scan_lds, s, v, pl.qcodes, pl.leaves,
                        pl.lstride, pl.lcount, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, pl.gdist, pl.cstride, pl.sel_pos,
                        pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count);
@@ -966,7 +992,6 @@ extern "C" cuddle_status cuddle_scan_batch(cuddle_index *idx, const float *queri
     ST_TRY(use_device(idx->device));
     if (dim != idx->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, idx->dev.dim);
     if (n_queries == 0) return CUDDLE_OK;
-    if (idx->dev.code_kind != CUDDLE_CODE_BINARY) return fail(CUDDLE_ERR_UNSUPPORTED, "RaBitQ scan is not built yet");
     Plan pl;
     ST_TRY(make_plan(idx, n_queries, 1, 1, 1, max_u32(leaf_count, n_queries), pl));
     HostIO io;
@@ -981,9 +1006,16 @@ extern "C" cuddle_status cuddle_scan_batch(cuddle_index *idx, const float *queri
         HIP_TRY(hipMemcpy(io.q, queries + (uint64_t)q0 * dim, (size_t)qc * dim * 4, hipMemcpyHostToDevice));
         ST_TRY(upload_leaves(idx, pl, leaves, leaf_stride, leaf_count, q0, qc));
         ST_TRY(launch_quantize(idx, pl, io.q, qc, nullptr));
-        size_t lds = scan_lds_bytes(idx->dev.dim, idx->dev.words, pl.lstride, 0, 0);
-        hipLaunchKernelGGL(scan_all_hamming_kernel, dim3(qc), dim3(256), lds, nullptr, idx->dev, pl.qcodes, pl.leaves,
-                           pl.lstride, pl.lcount, pl.lstride, d_pos, d_key, cand_stride, pl.cand_count);
+        if (idx->dev.code_kind == CUDDLE_CODE_BINARY) {
+            size_t lds = scan_lds_bytes(idx->dev.dim, idx->dev.words, pl.lstride, 0, 0);
+            hipLaunchKernelGGL(scan_all_hamming_kernel, dim3(qc), dim3(256), lds, nullptr, idx->dev, pl.qcodes, pl.leaves,
+                               pl.lstride, pl.lcount, pl.lstride, d_pos, d_key, cand_stride, pl.cand_count);
+        } else {
+            const float *rq = reinterpret_cast<const float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * idx->dev.dim;
+            size_t lds = rabitq_scan_lds_bytes(idx->dev.dim, pl.lstride, 0, 0);
+            hipLaunchKernelGGL(scan_all_rabitq_kernel, dim3(qc), dim3(256), lds, nullptr, idx->dev, rq, qn, pl.leaves,
+                               pl.lstride, pl.lcount, pl.lstride, d_pos, d_key, cand_stride, pl.cand_count);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(nullptr));
         HIP_TRY(hipMemcpy(out_cand_count + q0, pl.cand_count, (size_t)qc * 4, hipMemcpyDeviceToHost));

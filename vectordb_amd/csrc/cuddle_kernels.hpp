@@ -36,7 +36,8 @@ struct IndexDev {
     const float *vectors;         // [n_vectors][dim]
     const uint4 *codes;           // planar per-leaf binary codes (see relayout_codes_kernel)
     // RaBitQ
-    const float *rot_t;           // [dim][dim]
+    const float *rot_t;           // [dim][dim]  rotation_matrix_t (row i = output component i)
+    const float *rot;             // [dim][dim]  its transpose: rot[j][i] = rot_t[i][j]
     const uint32_t *rq_codes;     // planar per-leaf: word-major [words32][n] per leaf
     const float *rq_norm;         // [n_vectors]
     const float *rq_ipoo;         // [n_vectors]
