@@ -1,0 +1,179 @@
+"""GPU edge cases through the C ABI: leaf helpers on all tail lengths, error codes, empty and
+ragged inputs, shards with empty leaves, tie-heavy selections, the 10 000 rerank cap, the
+global spill path of the scan (more candidates than fit in LDS) and batch chunking."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from vectordb_amd import _ffi
+from vectordb_amd.builder import build_index
+from vectordb_amd.flat_index import FlatIndex
+from vectordb_amd.index import ClusteredIndex, DeviceIndex
+
+from helpers import clustered, queries_like, small_index
+from test_gpu_parity import _compare_full, _oracle
+
+pytestmark = pytest.mark.gpu
+L2, COS, DOT = _ffi.METRIC_L2, _ffi.METRIC_COSINE, _ffi.METRIC_DOT
+
+
+def _pairs(a, b, metric):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    out = np.zeros(a.shape[0], dtype=np.float32)
+    _ffi.check(_ffi.lib().cuddle_distance_pairs(_ffi.ptr(a), _ffi.ptr(b), a.shape[0], a.shape[1], metric, _ffi.ptr(out), 0))
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 100, 1023, 1024, 1025])
+def test_distance_all_lengths_bit_exact(gpu, n):  # simd_neon.rs:396-420 lengths, all three metrics
+    orc = _oracle()
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((37, n)).astype(np.float32)
+    b = rng.standard_normal((37, n)).astype(np.float32)
+    for metric in (L2, COS, DOT):
+        got = _pairs(a, b, metric)
+        exp = orc.distance_pairs(a, b, metric)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (n, metric)
+
+
+def test_distance_kats(gpu):  # simd_neon.rs:423-438, tests/integration_tests.rs:3-30
+    assert _pairs([[2.0]], [[3.0]], L2)[0] == 1.0 and _pairs([[2.0]], [[3.0]], DOT)[0] == -6.0
+    v = [[1.0, 2.0, 3.0, 4.0]]
+    assert _pairs(v, v, L2)[0] == 0.0 and abs(_pairs(v, v, COS)[0]) < 1e-6
+    a, b = [[1.0, 2.0, 3.0]], [[4.0, 5.0, 6.0]]
+    assert _pairs(a, b, L2)[0] == 27.0 and _pairs(a, b, DOT)[0] == -32.0 and 0.0 <= _pairs(a, b, COS)[0] <= 2.0
+
+
+def test_quantize_and_hamming_kats(gpu):  # binary.rs:193-291
+    orc = _oracle()
+    rng = np.random.default_rng(0)
+    for d in (4, 8, 63, 64, 65, 128, 960, 1024):
+        v = rng.standard_normal((50, d)).astype(np.float32)
+        codes = np.zeros((50, (d + 63) // 64), dtype=np.uint64)
+        _ffi.check(_ffi.lib().cuddle_binary_quantize(_ffi.ptr(v), 50, d, 0.0, _ffi.ptr(codes), 0))
+        assert np.array_equal(codes, orc.binary_quantize(v, 0.0))
+        out = np.zeros(25, dtype=np.uint32)
+        a, b = np.ascontiguousarray(codes[:25]), np.ascontiguousarray(codes[25:])
+        _ffi.check(_ffi.lib().cuddle_hamming_pairs(_ffi.ptr(a), _ffi.ptr(b), 25, codes.shape[1], _ffi.ptr(out), 0))
+        assert np.array_equal(out, orc.hamming_pairs(a, b))
+    one = np.ones((1, 64), dtype=np.float32)
+    c1 = np.zeros((1, 1), dtype=np.uint64)
+    c2 = np.zeros((1, 1), dtype=np.uint64)
+    _ffi.lib().cuddle_binary_quantize(_ffi.ptr(one), 1, 64, 0.0, _ffi.ptr(c1), 0)
+    _ffi.lib().cuddle_binary_quantize(_ffi.ptr(-one), 1, 64, 0.0, _ffi.ptr(c2), 0)
+    out = np.zeros(1, dtype=np.uint32)
+    _ffi.lib().cuddle_hamming_pairs(_ffi.ptr(c1), _ffi.ptr(c2), 1, 1, _ffi.ptr(out), 0)
+    assert out[0] == 64  # binary.rs:235-246
+
+
+def test_error_codes(gpu):
+    x, fi = small_index(n=600, d=8, n_clusters=6, branching=4, leaf=20)
+    dev = DeviceIndex(fi, gpu)
+    q = queries_like(x, 4, 1)
+    with pytest.raises(_ffi.CuddleError) as e:
+        dev.search_batch(q[:, :7], 5, 2, 3)
+    assert e.value.status == _ffi.ERR_BAD_DIM            # hierarchical.rs:337
+    for k, p, rf in ((0, 2, 3), (5, 0, 3), (5, 2, 0)):
+        with pytest.raises(_ffi.CuddleError) as e:
+            dev.search_batch(q, k, p, rf)
+        assert e.value.status == _ffi.ERR_BAD_ARG        # k-1 underflow, hierarchical.rs:651
+    with pytest.raises(_ffi.CuddleError) as e:
+        dev.search_batch(q, 100, 2, 200, _ffi.SEARCH_STATS_VARIANT)  # uncapped 20000 > 16384
+    assert e.value.status == _ffi.ERR_UNSUPPORTED
+    ids, dist, cnt = dev.search_batch(q[:0], 5, 2, 3)    # empty batch
+    assert ids.shape == (0, 5)
+    # the handle still works after errors
+    _compare_full(fi, dev, q, 5, 2, 3)
+
+
+def test_fewer_results_than_k_and_single_leaf(gpu):
+    x = clustered(40, 12, 2, 3)
+    fi = build_index(x, 4, 30, "l2", 5, seed=1)          # 40 <= 2*30 -> one leaf, which is the only root
+    assert fi.n_nodes == 1
+    dev = DeviceIndex(fi, gpu)
+    q = queries_like(x, 6, 2)
+    _compare_full(fi, dev, q, 100, 3, 2)                  # at most 40 results
+    ids, dist, cnt = dev.search_batch(q, 100, 3, 2)
+    assert np.all(cnt == 40)
+    ci = ClusteredIndex(fi, gpu)
+    r = ci.search(q[0], 5, 1, 1)
+    assert len(r) == 5 and all(r[i][1] <= r[i + 1][1] for i in range(4))
+    r2, st = ci.search_with_stats(q[0], 5, 1, 1)
+    assert st.total_leaves == 1 and st.leaves_searched == 1 and st.vectors_scanned_binary == 40
+
+
+def test_empty_leaves_and_shards(gpu):
+    orc = _oracle()
+    x, fi = small_index(n=3000, d=24, n_clusters=15, branching=6, leaf=25)
+    q = queries_like(x, 32, 4)
+    for world in (2, 5):
+        for rank in range(world):
+            sh = fi.shard(rank, world)
+            _compare_full(sh, DeviceIndex(sh, gpu), q, 10, 4, 4)
+    # a shard with no vectors at all: every query returns nothing (hierarchical.rs:452-454)
+    empty = fi.shard(0, 1)
+    empty = FlatIndex(dim=fi.dim, metric=fi.metric, code_kind=fi.code_kind, centroids=fi.centroids,
+                      child_offsets=fi.child_offsets, children=fi.children, roots=fi.roots,
+                      vec_offsets=np.zeros_like(fi.vec_offsets), ids=fi.ids[:0], vectors=fi.vectors[:0],
+                      threshold=fi.threshold, codes=fi.codes[:0])
+    ids, dist, cnt = DeviceIndex(empty, gpu).search_batch(q, 10, 4, 4)
+    assert np.all(cnt == 0) and np.all(ids == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(np.isinf(dist))
+
+
+def test_tie_heavy_selection(gpu):
+    """8-bit codes on integer data: almost every Hamming value is shared by many candidates, so
+    the selection boundary is always inside a tie class (scan-order rule)."""
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 4, (4000, 8)).astype(np.float32)
+    fi = build_index(x, 8, 40, "l2", 6, seed=2)
+    dev = DeviceIndex(fi, gpu)
+    q = rng.integers(0, 4, (40, 8)).astype(np.float32)
+    _compare_full(fi, dev, q, 10, 6, 3)
+    _compare_full(fi, dev, q, 3, 10, 7)
+
+
+def test_rerank_cap_and_spill_path(gpu):
+    """probes large enough that one query scans > 24576 candidates (the LDS capacity of the scan
+    kernel: distances go to the global spill buffer) and k*rerank_factor hits the 10 000 cap."""
+    x = clustered(70000, 32, 200, 8, sigma=0.3)
+    fi = build_index(x, 100, 50, "l2", 6, seed=4)
+    dev = DeviceIndex(fi, gpu)
+    q = queries_like(x, 6, 6)
+    ids, dist, cnt, st = dev.search_batch(q, 100, 800, 150, want_stats=True)
+    assert st["max_candidates"] > 24576, st
+    assert st["vectors_reranked"] == 6 * 10000          # min(k*rf, 10000), hierarchical.rs:447
+    _compare_full(fi, dev, q, 100, 800, 150)
+
+
+def test_batch_larger_than_one_chunk(gpu):
+    x, fi = small_index(n=3000, d=16, n_clusters=20, branching=6, leaf=30)
+    dev = DeviceIndex(fi, gpu)
+    q = queries_like(x, 5000, 21)                        # > 4096: two chunks
+    ids, dist, cnt = dev.search_batch(q, 5, 3, 4)
+    sel = np.r_[0:40, 4090:4110, 4960:5000]
+    ids2, dist2, cnt2 = dev.search_batch(q[sel], 5, 3, 4)
+    assert np.array_equal(ids[sel], ids2) and np.array_equal(dist[sel], dist2)
+    orc = _oracle()
+    oi = orc.OracleIndex(fi)
+    for i in (0, 4095, 4096, 4999):
+        r = oi.search(q[i], 5, 3, 4)
+        assert np.array_equal(ids[i], r["ids"]) and np.array_equal(dist[i], r["dist"])
+
+
+def test_device_pointer_entry_point_matches_host_one(gpu):
+    import torch
+
+    x, fi = small_index(n=3000, d=16, n_clusters=20, branching=6, leaf=30)
+    dev = DeviceIndex(fi, gpu)
+    q = queries_like(x, 100, 2)
+    ids, dist, cnt = dev.search_batch(q, 10, 3, 4)
+    dq = torch.from_numpy(q).cuda()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        tid, tdist, tcnt = dev.search_batch_device(dq, 10, 3, 4, _ffi.SEARCH_TIME_STAGES)
+    s.synchronize()
+    assert np.array_equal(tid.cpu().numpy().view(np.uint64), ids) and np.array_equal(tdist.cpu().numpy(), dist)
+    t = dev.stage_times()
+    assert t["searches"] == 1 and t["scan"] > 0.0
