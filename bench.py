@@ -250,8 +250,14 @@ def main():
     n_timed = max(stage["searches"], 1)
     scan_ms = stage["scan"] / n_timed
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", f"pmc_hbm_traffic_{args.config}.json")
+    if world == 1 and os.path.exists(pmc_path):  # measured separately under rocprofv3 --pmc (it cannot run inside this process)
+        pmc = json.load(open(pmc_path))
+        traffic = pmc["kernels"]["scan_select_hamming_kernel"]["traffic_bytes_per_launch"]
+        traffic_src = os.path.relpath(pmc_path, ROOT)
     roofline = dict(bound="hbm", kernel="scan_select_hamming_kernel", achieved=achieved, peak=HBM_PEAK_GBPS,
-                    unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=None,
+                    unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=scan_bytes, avg_launch_ms=scan_ms,
                     stage_ms_per_step={n: stage[n] / n_timed for n in _ffi.STAGE_NAMES},
                     rerank_GBps=(rerank_bytes / (stage["rerank"] / n_timed * 1e-3) / 1e9) if stage["rerank"] > 0 else 0.0,
@@ -290,6 +296,7 @@ def main():
         "leaves_per_query": stats["leaves_searched"] / nq,
         "reranked_per_query": stats["vectors_reranked"] / nq,
         "route_fallbacks_per_batch": stats["route_fallbacks"],
+        "max_candidates": stats["max_candidates"],
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

@@ -117,6 +117,7 @@ struct Plan {
     uint32_t kc_cap = 0;    // prefilter candidates per query (probes + margin)
     float *qcent = nullptr, *qsq = nullptr, *rc_dist = nullptr, *rc_max = nullptr;
     uint32_t *rc_pos = nullptr, *rflag = nullptr;
+    uint32_t *order = nullptr; // queries by decreasing candidate count
     size_t bytes = 0;
 };
 
@@ -538,6 +539,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     pl.kc_cap = (uint32_t)align_up((size_t)pl.probes + route_margin(pl.probes), 32);
     size_t o_qcent = carve(qc * v.dim * 4), o_qsq = carve(qc * 4);
     size_t o_rcp = carve(qc * pl.kc_cap * 4), o_rcd = carve(qc * pl.kc_cap * 4), o_rcm = carve(qc * 4), o_rfl = carve(qc * 4);
+    size_t o_ord = carve(qc * 4);
     pl.bytes = off;
     ST_TRY(ix->ws.ensure(pl.bytes));
     char *b = static_cast<char *>(ix->ws.p);
@@ -552,6 +554,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     pl.qcent = (float *)(b + o_qcent); pl.qsq = (float *)(b + o_qsq);
     pl.rc_pos = (uint32_t *)(b + o_rcp); pl.rc_dist = (float *)(b + o_rcd); pl.rc_max = (float *)(b + o_rcm);
     pl.rflag = (uint32_t *)(b + o_rfl);
+    pl.order = (uint32_t *)(b + o_ord);
     return CUDDLE_OK;
 }
 
@@ -665,12 +668,17 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
 // Scan + phase-1 selection for the leaf lists in pl.leaves / pl.lcount.
 static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32_t nq, hipStream_t s) {
     const IndexDev &v = ix->dev;
+    // longest queries first (nq <= kMaxChunk = 4096 fits one sorting block)
+    hipLaunchKernelGGL(cand_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, pl.leaves, pl.lstride, pl.lcount, nq,
+                       pl.cand_count);
+    hipLaunchKernelGGL(order_by_work_kernel, dim3(1), dim3(1024), (size_t)host_next_pow2(nq) * 8, s, pl.cand_count, nq,
+                       pl.order);
     if (v.code_kind == CUDDLE_CODE_RABITQ) {
         const float *rq = reinterpret_cast<const float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
         hipLaunchKernelGGL(scan_select_rabitq_kernel, dim3(nq), dim3(kScanThreads), pl.scan_lds, s, v, rq, qn, pl.leaves,
                            pl.lstride, pl.lcount, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap,
                            reinterpret_cast<float *>(pl.gdist), pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count,
-                           pl.cand_count);
+                           pl.cand_count, pl.order);
         hipLaunchKernelGGL(selection_sort_f32_kernel, dim3(nq), dim3(256), (size_t)host_next_pow2(pl.sstride) * 16, s,
                            pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count);
         HIP_TRY(hipGetLastError());
@@ -678,7 +686,7 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
     }
     hipLaunchKernelGGL(scan_select_hamming_kernel, dim3(nq), dim3(kScanThreads), pl.scan_lds, s, v, pl.qcodes, pl.leaves,
                        pl.lstride, pl.lcount, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, pl.gdist, pl.cstride, pl.sel_pos,
-                       pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count);
+                       pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, pl.order);
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
 }

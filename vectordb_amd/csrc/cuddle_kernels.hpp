@@ -528,6 +528,38 @@ __device__ __forceinline__ void scan_tiles(const IndexDev &ix, const ScanLds &s,
     }
 }
 
+// Candidates per query = sum of the sizes of its reached leaves (one wave per query).
+__global__ void __launch_bounds__(256)
+cand_count_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const uint32_t *lcount, uint32_t nq,
+                  uint32_t *cand_count) {
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const uint32_t nl = min(lcount[q], lstride);
+    uint32_t c = 0;
+    for (uint32_t t = lane; t < nl; t += 64) {
+        uint32_t node = leaves[(uint64_t)q * lstride + t];
+        c += ix.vec_off[node + 1] - ix.vec_off[node];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) cand_count[q] = c;
+}
+
+// order[i] = the query with the i-th most candidates. The scan kernels process queries in this
+// order so that the longest blocks start first and the tail of the launch is made of short ones.
+// One block, nq <= 4096; dynamic LDS = next_pow2(nq) u64.
+__global__ void __launch_bounds__(1024)
+order_by_work_kernel(const uint32_t *cand_count, uint32_t nq, uint32_t *order) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);
+    const uint32_t npad = next_pow2(max(nq, 1u));
+    for (uint32_t i = threadIdx.x; i < npad; i += blockDim.x)
+        skeys[i] = i < nq ? (((uint64_t)(~cand_count[i]) << 32) | i) : ~0ull;
+    __syncthreads();
+    block_bitonic_sort_u64(skeys, npad);
+    for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) order[i] = (uint32_t)skeys[i];
+}
+
 // One block per query. Phase 1 streams the planar codes of every reached leaf (tiles of 64
 // vectors, lane = vector), XOR + popcount against the query code, and keeps each candidate's
 // Hamming distance as u16 (LDS when the query's candidates fit in dist_cap, else the global
@@ -541,9 +573,10 @@ __global__ void __launch_bounds__(512)
 scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *leaves, uint32_t lstride,
                            const uint32_t *lcount, uint32_t lcap, uint32_t tcap, uint32_t rerank_k, uint32_t dist_cap,
                            uint16_t *gdist, uint32_t gdist_stride, uint32_t *sel_pos, uint32_t *sel_key,
-                           uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count) {
+                           uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count, const uint32_t *order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const uint32_t q = order ? order[blockIdx.x] : blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const uint32_t D = ix.dim, W = ix.words;
     ScanLds s = scan_lds_carve(smem, D, W, lcap, tcap);
     const uint32_t nl = min(lcount[q], lcap);

@@ -123,9 +123,10 @@ __global__ void __launch_bounds__(512)
 scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_all, const uint32_t *leaves,
                           uint32_t lstride, const uint32_t *lcount, uint32_t lcap, uint32_t tcap, uint32_t rerank_k,
                           uint32_t dist_cap, float *gest, uint32_t gest_stride, uint32_t *sel_pos, uint32_t *sel_key,
-                          uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count) {
+                          uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count, const uint32_t *order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const uint32_t q = order ? order[blockIdx.x] : blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const uint32_t D = ix.dim, W32 = ix.words32;
     RabitqLds r = rabitq_lds_carve(smem, D, lcap, tcap);
     const ScanLds &s = r.s;
