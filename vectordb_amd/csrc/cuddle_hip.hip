@@ -138,6 +138,7 @@ struct cuddle_index {
     uint64_t index_bytes = 0;
     uint32_t n_levels = 0, max_children = 0, max_leaf = 0, n_leaves = 0;
     float threshold = 0.f; // BinaryQuantizer::threshold
+    uint32_t n_cus = 256;
     std::vector<uint32_t> level_width;
     std::vector<LevelGemm> lvl;
     std::vector<uint32_t> level_leaves; // leaf nodes per level
@@ -308,6 +309,10 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
         ~Guard() { delete p; }
     } guard{ix};
     ix->device = device_id;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ix->n_cus = (uint32_t)prop.multiProcessorCount;
+    }
     ix->threshold = d->threshold;
     ix->n_levels = n_levels;
     ix->level_width = level_width;
@@ -637,11 +642,22 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         if (use_gemm) {
             const uint32_t n = g.n, kc = std::min(n, pl.kc_cap);
             hipLaunchKernelGGL(center_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, pl.qcent, pl.qsq);
-            const uint32_t gx = (n + kGemmBN - 1) / kGemmBN, gy = (nq + kGemmBM - 1) / kGemmBM;
-            hipLaunchKernelGGL(route_gemm_kernel, dim3(8 * ((gx + 7) / 8) * gy), dim3(256), kGemmLdsBytes, s, pl.qcent, pl.qsq,
-                               g.table, g.sqn, nq, n, v.dim, v.metric, pl.fdist, pl.fstride, gx, gy);
-            hipLaunchKernelGGL(route_prefilter_kernel, dim3(nq), dim3(256), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,
-                               pl.kc_cap, pl.rc_max);
+            // column-tile width 128 or 64: whichever needs fewer rounds of blocks over the CUs (weighted by tile size)
+            const uint32_t gy = (nq + kGemmBM - 1) / kGemmBM, gx2 = (n + 127) / 128, gx1 = (n + 63) / 64;
+            const uint32_t cus = ix->n_cus;
+            const uint32_t cost2 = 2 * ((gx2 * gy + cus - 1) / cus), cost1 = (gx1 * gy + cus - 1) / cus;
+            if (cost1 < cost2)
+                hipLaunchKernelGGL(route_gemm_kernel<1>, dim3(8 * ((gx1 + 7) / 8) * gy), dim3(256), route_gemm_lds_bytes(1), s,
+                                   pl.qcent, pl.qsq, g.table, g.sqn, nq, n, v.dim, v.metric, pl.fdist, pl.fstride, gx1, gy);
+            else
+                hipLaunchKernelGGL(route_gemm_kernel<2>, dim3(8 * ((gx2 + 7) / 8) * gy), dim3(256), route_gemm_lds_bytes(2), s,
+                                   pl.qcent, pl.qsq, g.table, g.sqn, nq, n, v.dim, v.metric, pl.fdist, pl.fstride, gx2, gy);
+            if (n <= (uint32_t)kPrefKpt * kPrefThreads)
+                hipLaunchKernelGGL(route_prefilter_reg_kernel, dim3(nq), dim3(kPrefThreads), 0, s, pl.fdist, pl.fstride, n, kc,
+                                   pl.rc_pos, pl.kc_cap, pl.rc_max);
+            else
+                hipLaunchKernelGGL(route_prefilter_kernel, dim3(nq), dim3(256), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,
+                                   pl.kc_cap, pl.rc_max);
             hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                g.nodes, pl.rc_pos, pl.kc_cap, kc, pl.rc_dist);
             hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(kc), pl.probes), s,
@@ -650,8 +666,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                                pl.rflag, &ix->d_stats->fallbacks);
             only = pl.rflag; // queries whose selection could not be proven exact fall through to the exact kernels
         }
-        if (!keep_all)
-            hipLaunchKernelGGL(route_dist_kernel, dim3((bound + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
+        if (!keep_all) // after the MFMA path only the (rare) flagged queries do work here: few blocks per query
+            hipLaunchKernelGGL(route_dist_kernel, dim3(use_gemm ? 4 : std::min<uint32_t>((bound + 63) / 64, 64), nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                pl.frontier[cur], pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, only);
         hipLaunchKernelGGL(route_select_kernel, dim3(nq), dim3(256), route_select_lds_bytes(scap), s, v, pl.frontier[cur],
                            pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, scap,

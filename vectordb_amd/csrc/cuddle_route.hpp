@@ -136,7 +136,8 @@ __global__ void route_init_kernel(const uint32_t *roots, uint32_t n_roots, uint3
 // Nothing is computed for a query whose nodes are all kept (n <= probes, :395-397).
 // only_flag != null: only queries with only_flag[q] != 0 are processed. shared_fr != null: every
 // query's frontier is the list shared_fr[0..shared_n) (frontier / fcount are not read).
-// grid = (ceil(bound/64), nq), block = 256: one 4-lane group per (query, node).
+// grid = (gx, nq) with any gx >= 1 (blocks stride over the nodes), block = 256: one 4-lane group
+// per (query, node).
 __global__ void __launch_bounds__(256)
 route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, uint32_t fstride,
                   const uint32_t *fcount, const uint32_t *shared_fr, uint32_t shared_n, float *fdist, uint32_t probes,
@@ -163,13 +164,15 @@ route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, u
         }
         return;
     }
-    const uint32_t j = blockIdx.x * 64 + (threadIdx.x >> 2);
     const uint32_t sub = threadIdx.x & 3;
-    const bool act = j < n;
-    const uint32_t node = fr[act ? j : 0];
     const bool vec = (D & 3) == 0;
-    float d = distance_group4(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, vec);
-    if (act && sub == 0) fd[j] = d;
+    for (uint32_t j0 = blockIdx.x * 64; j0 < n; j0 += gridDim.x * 64) { // block-uniform trip count
+        const uint32_t j = j0 + (threadIdx.x >> 2);
+        const bool act = j < n;
+        const uint32_t node = fr[act ? j : 0];
+        float d = distance_group4(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, vec);
+        if (act && sub == 0) fd[j] = d;
+    }
 }
 
 inline size_t route_select_lds_bytes(uint32_t scap) {
@@ -278,28 +281,32 @@ center_queries_kernel(const float *queries, const float *mu, uint32_t nq, uint32
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32;
+constexpr int kGemmBM = 128, kGemmBK = 32;
 constexpr int kGemmLdsRow = 20; // 16 floats of one (row, k-parity) + 4 pad: conflict-free ds_read_b128
-constexpr size_t kGemmLdsBytes = 2 /*A,B*/ * 2 /*parity*/ * 128 * kGemmLdsRow * sizeof(float);
+inline size_t route_gemm_lds_bytes(int nt) { return (size_t)2 /*parity*/ * (kGemmBM + 64 * nt) * kGemmLdsRow * sizeof(float); }
 
 // Approximate distances of every query to every node of one level:
 //   S = A * B^T on the f32 matrix cores (A = centred queries [M][K], B = level table [N][K]),
 //   L2:     d~ = (|a|^2 + |b|^2) - 2 S
 //   DOT:    d~ = -S
 //   COSINE: d~ = 1 - S / (|a| |b|)
-// Block tile 128 x 128, K step 32, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles of
-// 32 x 32 (v_mfma_f32_32x32x2_f32: lane l supplies A[row l&31][k = l>>5] and B[k = l>>5][col l&31]).
+// Block tile 128 x (64 NT), K step 32, 4 waves as 2 x 2, each wave 64 x (32 NT) = 2 x NT MFMA tiles
+// of 32 x 32 (v_mfma_f32_32x32x2_f32: lane l supplies A[row l&31][k = l>>5] and B[k = l>>5][col l&31]).
+// NT = 2 has the higher arithmetic intensity, NT = 1 twice the blocks: the host picks whichever
+// leaves fewer idle CUs in the last round of blocks.
 // LDS image per operand: [k parity h][row][s] with k = 2s + h, so a lane reads its 16 k-values of
 // a K step with four ds_read_b128. Global tiles are prefetched into registers one K step ahead.
 // Blocks are numbered so that the row blocks of one column panel share an XCD (its L2 keeps the
 // panel of B): id % 8 selects the XCD, panels x = 8 * xl + xcd belong to XCD xcd.
 // K must be a multiple of 4. out: [M][ostride].
+template <int NT>
 __global__ void __launch_bounds__(256)
 route_gemm_kernel(const float *A, const float *Asq, const float *B, const float *Bsq, uint32_t M, uint32_t N,
                   uint32_t K, uint32_t metric, float *out, uint32_t ostride, uint32_t gx, uint32_t gy) {
+    constexpr int BN = 64 * NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *As = reinterpret_cast<float *>(smem);            // [2][128][20]
-    float *Bs = As + 2 * 128 * kGemmLdsRow;                 // [2][128][20]
+    float *Bs = As + 2 * kGemmBM * kGemmLdsRow;             // [2][BN][20]
     const uint32_t id = blockIdx.x;
     const uint32_t xcd = id & 7, local = id >> 3;
     const uint32_t bx = (local / gy) * 8 + xcd, by = local % gy;
@@ -308,39 +315,38 @@ route_gemm_kernel(const float *A, const float *Asq, const float *B, const float 
     const uint32_t wr = w >> 1, wc = w & 1, r = lane & 31, h = lane >> 5;
     // global -> register staging: thread covers rows (tid>>3) + 32 i, floats 4 (tid&7) .. +3
     const uint32_t lr = tid >> 3, lc4 = tid & 7;
-    const float *ga[4], *gb[4];
+    const float *ga[4], *gb[2 * NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        uint32_t ra = min(by * kGemmBM + lr + 32 * i, M - 1), rb = min(bx * kGemmBN + lr + 32 * i, N - 1);
-        ga[i] = A + (uint64_t)ra * K + 4 * lc4;
-        gb[i] = B + (uint64_t)rb * K + 4 * lc4;
-    }
-    float4 pa[4], pb[4];
+    for (int i = 0; i < 4; ++i) ga[i] = A + (uint64_t)min(by * kGemmBM + lr + 32 * i, M - 1) * K + 4 * lc4;
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) gb[i] = B + (uint64_t)min(bx * BN + lr + 32 * i, N - 1) * K + 4 * lc4;
+    float4 pa[4], pb[2 * NT];
     auto load_tile = [&](uint32_t k0) {
         const bool in = k0 + 4 * lc4 < K;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            pa[i] = in ? *reinterpret_cast<const float4 *>(ga[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-            pb[i] = in ? *reinterpret_cast<const float4 *>(gb[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < 4; ++i) pa[i] = in ? *reinterpret_cast<const float4 *>(ga[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) pb[i] = in ? *reinterpret_cast<const float4 *>(gb[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t row = lr + 32 * i;
-            float *a0 = As + (0 * 128 + row) * kGemmLdsRow + 2 * lc4, *a1 = As + (1 * 128 + row) * kGemmLdsRow + 2 * lc4;
-            float *b0 = Bs + (0 * 128 + row) * kGemmLdsRow + 2 * lc4, *b1 = Bs + (1 * 128 + row) * kGemmLdsRow + 2 * lc4;
-            *reinterpret_cast<float2 *>(a0) = make_float2(pa[i].x, pa[i].z);
-            *reinterpret_cast<float2 *>(a1) = make_float2(pa[i].y, pa[i].w);
-            *reinterpret_cast<float2 *>(b0) = make_float2(pb[i].x, pb[i].z);
-            *reinterpret_cast<float2 *>(b1) = make_float2(pb[i].y, pb[i].w);
+            *reinterpret_cast<float2 *>(As + (0 * kGemmBM + row) * kGemmLdsRow + 2 * lc4) = make_float2(pa[i].x, pa[i].z);
+            *reinterpret_cast<float2 *>(As + (1 * kGemmBM + row) * kGemmLdsRow + 2 * lc4) = make_float2(pa[i].y, pa[i].w);
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+            const uint32_t row = lr + 32 * i;
+            *reinterpret_cast<float2 *>(Bs + (0 * BN + row) * kGemmLdsRow + 2 * lc4) = make_float2(pb[i].x, pb[i].z);
+            *reinterpret_cast<float2 *>(Bs + (1 * BN + row) * kGemmLdsRow + 2 * lc4) = make_float2(pb[i].y, pb[i].w);
         }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
     load_tile(0);
@@ -349,29 +355,33 @@ route_gemm_kernel(const float *A, const float *Asq, const float *B, const float 
         store_tile();
         __syncthreads();
         if (k0 + kGemmBK < K) load_tile(k0 + kGemmBK);
-        float4 fa[2][4], fb[2][4];
+        float4 fa[2][4], fb[NT][4];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const float4 *pa4 = reinterpret_cast<const float4 *>(As + (h * 128 + wr * 64 + t * 32 + r) * kGemmLdsRow);
-            const float4 *pb4 = reinterpret_cast<const float4 *>(Bs + (h * 128 + wc * 64 + t * 32 + r) * kGemmLdsRow);
+            const float4 *p4 = reinterpret_cast<const float4 *>(As + (h * kGemmBM + wr * 64 + t * 32 + r) * kGemmLdsRow);
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                fa[t][s4] = pa4[s4];
-                fb[t][s4] = pb4[s4];
-            }
+            for (int s4 = 0; s4 < 4; ++s4) fa[t][s4] = p4[s4];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 *p4 = reinterpret_cast<const float4 *>(Bs + (h * BN + wc * 32 * NT + t * 32 + r) * kGemmLdsRow);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) fb[t][s4] = p4[s4];
         }
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float a0 = e == 0 ? fa[0][s4].x : e == 1 ? fa[0][s4].y : e == 2 ? fa[0][s4].z : fa[0][s4].w;
-                float a1 = e == 0 ? fa[1][s4].x : e == 1 ? fa[1][s4].y : e == 2 ? fa[1][s4].z : fa[1][s4].w;
-                float b0 = e == 0 ? fb[0][s4].x : e == 1 ? fb[0][s4].y : e == 2 ? fb[0][s4].z : fb[0][s4].w;
-                float b1 = e == 0 ? fb[1][s4].x : e == 1 ? fb[1][s4].y : e == 2 ? fb[1][s4].z : fb[1][s4].w;
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                float av[2], bv[NT];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) av[t] = e == 0 ? fa[t][s4].x : e == 1 ? fa[t][s4].y : e == 2 ? fa[t][s4].z : fa[t][s4].w;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bv[t] = e == 0 ? fb[t][s4].x : e == 1 ? fb[t][s4].y : e == 2 ? fb[t][s4].z : fb[t][s4].w;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
             }
         }
     }
@@ -379,8 +389,8 @@ route_gemm_kernel(const float *A, const float *Asq, const float *B, const float 
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const uint32_t gn = bx * kGemmBN + wc * 64 + nt * 32 + r;
+        for (int nt = 0; nt < NT; ++nt) {
+            const uint32_t gn = bx * BN + wc * 32 * NT + nt * 32 + r;
             if (gn >= N) continue;
             const float bs = Bsq[gn];
 #pragma unroll
@@ -426,6 +436,100 @@ route_prefilter_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_
         n, T, budget, [&](uint32_t i) { return f32_key(fd[i]); },
         [&](uint32_t i, uint32_t, uint32_t rank) { if (rank < cstride) cp[rank] = i; }, wtmp);
     if (threadIdx.x == 0) cand_max[q] = f32_from_key(T);
+}
+
+constexpr int kPrefKpt = 32, kPrefThreads = 512; // register-resident prefilter: n <= 32 * 512
+
+// Same result as route_prefilter_kernel for levels of at most kPrefKpt * kPrefThreads nodes, with
+// the keys read once and kept in registers: block min/max first (radix passes whose digit is the
+// same for every key are skipped: no counting, no same-address atomics), then the remaining
+// passes from registers; the winners are written in any order (which ties at the threshold are
+// kept is free: every unselected node still has d~ >= cand_max, which is all the proof needs).
+__global__ void __launch_bounds__(kPrefThreads)
+route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_t kc, uint32_t *cand_pos,
+                           uint32_t cstride, float *cand_max) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t misc[4];
+    __shared__ uint32_t wred[2 * (kPrefThreads / 64)];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float *fd = fdist + (uint64_t)q * fstride;
+    uint32_t keys[kPrefKpt];
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int t = 0; t < kPrefKpt; ++t) {
+        const uint32_t i = t * kPrefThreads + tid;
+        keys[t] = i < n ? f32_key(fd[i]) : 0xFFFFFFFFu;
+        if (i < n) {
+            kmin = min(kmin, keys[t]);
+            kmax = max(kmax, keys[t]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+    }
+    if (lane == 0) {
+        wred[w] = kmin;
+        wred[kPrefThreads / 64 + w] = kmax;
+    }
+    if (tid < 2) misc[2 + tid] = 0; // winner counters
+    __syncthreads();
+    for (uint32_t v = 0; v < kPrefThreads / 64; ++v) {
+        kmin = min(kmin, wred[v]);
+        kmax = max(kmax, wred[kPrefThreads / 64 + v]);
+    }
+    uint32_t prefix = 0, want = kc;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if ((kmin >> shift) == (kmax >> shift)) { // every key has this digit (and all higher bits) in common
+            prefix |= ((kmin >> shift) & 255u) << shift;
+            continue;
+        }
+        for (uint32_t i = tid; i < 256; i += kPrefThreads) hist[i] = 0;
+        __syncthreads();
+        const uint32_t himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+#pragma unroll
+        for (int t = 0; t < kPrefKpt; ++t) {
+            const uint32_t i = t * kPrefThreads + tid;
+            if (i < n && (keys[t] & himask) == prefix) atomicAdd(&hist[(keys[t] >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const uint32_t s4 = h0 + h1 + h2 + h3;
+            const uint32_t incl = wave_inclusive_sum(s4);
+            const uint64_t hit = __ballot(incl >= want);
+            const uint32_t first = hit ? (uint32_t)__ffsll((unsigned long long)hit) - 1 : 63u;
+            if (tid == first) {
+                uint32_t cum = incl - s4, b = 4 * tid;
+                if (cum + h0 < want) { cum += h0; ++b;
+                    if (cum + h1 < want) { cum += h1; ++b;
+                        if (cum + h2 < want) { cum += h2; ++b; } } }
+                misc[0] = prefix | (b << shift);
+                misc[1] = want - cum;
+            }
+        }
+        __syncthreads();
+        prefix = misc[0];
+        want = misc[1];
+        __syncthreads();
+    }
+    const uint32_t T = prefix, budget = want, n_lt = kc - budget;
+    uint32_t *cp = cand_pos + (uint64_t)q * cstride;
+#pragma unroll
+    for (int t = 0; t < kPrefKpt; ++t) {
+        const uint32_t i = t * kPrefThreads + tid;
+        if (i < n) {
+            if (keys[t] < T) {
+                const uint32_t slot = atomicAdd(&misc[2], 1u);
+                if (slot < cstride) cp[slot] = i;
+            } else if (keys[t] == T) {
+                const uint32_t ts = atomicAdd(&misc[3], 1u);
+                if (ts < budget && n_lt + ts < cstride) cp[n_lt + ts] = i;
+            }
+        }
+    }
+    if (tid == 0) cand_max[q] = f32_from_key(T);
 }
 
 // Exact distance(query, centroid, metric) of the prefiltered nodes (levels on this path hold more
