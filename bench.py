@@ -52,6 +52,15 @@ CONFIGS = {
                    latent_dim=24,
                    label="SIFT1M-shaped synthetic (1M x 128 integer-valued f32: two-level Gaussian mixture of intrinsic "
                          "dimension 24 embedded linearly in 128-d)"),
+    # one GPU's share of the leaf-sharded 100M / 1B x 128-d configs (index by construction, built on the device)
+    "shard12m": dict(n=12_500_000, dim=128, n_queries=4096, k=10, metric="l2", style="sift", probes=100,
+                     rerank_sweep=[5, 10, 25, 50, 100, 200], code_kind="binary", tree=(50, 3, 100), gt_queries=1000,
+                     label="one of 8 leaf shards of a synthetic 100M x 128 index: 12.5M x 128 integer-valued f32, "
+                           "hierarchical Gaussian, tree by construction (50-way x 3 levels, 100-vector leaves)"),
+    "shard125m": dict(n=125_000_000, dim=128, n_queries=4096, k=10, metric="l2", style="sift", probes=100,
+                      rerank_sweep=[5, 10, 25, 50, 100, 200], code_kind="binary", tree=(100, 3, 125), gt_queries=1000,
+                      label="one of 8 leaf shards of a synthetic 1B x 128 index: 125M x 128 integer-valued f32 "
+                            "(2 GB codes + 64 GB fp32 in HBM), tree by construction (100-way x 3 levels, 125-vector leaves)"),
     "tiny": dict(n=20_000, dim=64, n_queries=256, k=10, metric="l2", style="gist", probes=8,
                  rerank_sweep=[5, 10, 25, 50, 100], branching=16, leaf=50, code_kind="binary", latent_dim=0,
                  label="tiny synthetic (20k x 64)"),
@@ -141,7 +150,21 @@ def main():
     fi = None
     gt = None
     t_setup = time.perf_counter()
-    if rank == 0:
+    dev_index = None
+    if "tree" in cfg:
+        # large shard: generated and indexed on the device, never copied through the host
+        from vectordb_amd.synthetic import build_tree_index_on_device
+        assert world == 1, "the shard configs measure one GPU's share"
+        fanout, levels, leaf_size = cfg["tree"]
+        log(f"generating {cfg['label']}")
+        dti, queries = build_tree_index_on_device(cfg["dim"], fanout, levels, leaf_size, device, seed=0xC0DD1E,
+                                                  n_queries=cfg["n_queries"])
+        log("ground truth (GPU brute force) on a query sample")
+        gq = cfg.get("gt_queries", cfg["n_queries"])
+        gt = brute_force_topk(dti.vectors, queries[:gq], k, cfg["metric"], chunk=1 << 20).cpu().numpy()
+        dev_index = dti.create(local_rank)
+        log(f"index: {dti.centroids.shape[0]} nodes, {dti.n_vectors} vectors, threshold {dti.threshold:.6g}")
+    elif rank == 0:
         log(f"generating {cfg['label']}: n={cfg['n']} dim={cfg['dim']}")
         base, queries = synthetic_mixture(cfg["n"], cfg["dim"], seed=0xC0DD1E, device=device, style=cfg["style"],
                                           n_queries=cfg["n_queries"], latent_dim=cfg["latent_dim"])
@@ -162,8 +185,9 @@ def main():
     if world > 1:
         dist.broadcast(queries, src=0)
         fi = broadcast_flat(fi, 0, device)
-    shard = fi.shard(rank, world)
-    dev_index = DeviceIndex(shard, local_rank)
+    if dev_index is None:
+        shard = fi.shard(rank, world)
+        dev_index = DeviceIndex(shard, local_rank)
     log(f"setup {time.perf_counter() - t_setup:.1f} s; device bytes {dev_index.device_bytes / 1e9:.2f} GB")
 
     flags = _ffi.SEARCH_TIME_STAGES
@@ -189,7 +213,7 @@ def main():
         ids, _, _ = step()
         torch.cuda.synchronize()
         if rank == 0:
-            r = recall_at_k(ids.cpu().numpy(), gt, k)
+            r = recall_at_k(ids.cpu().numpy()[:len(gt)], gt, k)
             sweep.append((rf, r))
             log(f"probes={probes} rerank_factor={rf}: recall@{k} = {r:.4f}")
         flag = torch.tensor([1 if (rank == 0 and sweep[-1][1] >= 0.95) else 0], device=device)
@@ -241,7 +265,7 @@ def main():
         return
     ids, _, _ = step()
     torch.cuda.synchronize()
-    recall = recall_at_k(ids.cpu().numpy(), gt, k)
+    recall = recall_at_k(ids.cpu().numpy()[:len(gt)], gt, k)
 
     # ---- roofline of the dominant kernel (the Hamming scan + select) -----------------------------
     code_bytes = 8 * ((cfg["dim"] + 63) // 64)
@@ -265,7 +289,7 @@ def main():
                          "across queries may be served on-die; the rate is algorithmic bytes per second")
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and fi is not None:
         log("CPU baseline (oracle port, OpenMP)")
         cpu, cpu_ids, sample = cpu_baseline(fi, queries.cpu().numpy(), k, probes, chosen)
         same = bool(np.array_equal(cpu_ids[:sample].astype(np.int64), ids.cpu().numpy()[:sample])) if world == 1 else None
@@ -286,7 +310,7 @@ def main():
         "dtype": "u64 xor/popcount scan + f32 rerank",
         "data": "synthetic",
         "config": {"workload": cfg["label"] + f", L2, k={k}, {nq}-query batch, probes_per_level={probes}, "
-                               f"rerank_factor={chosen}, branching {cfg['branching']} / leaf {cfg['leaf']}",
+                               f"rerank_factor={chosen}" + (f", branching {cfg['branching']} / leaf {cfg['leaf']}" if "branching" in cfg else ""),
                    "name": args.config, "binary_threshold": args.threshold, "parallelism": f"leaf-sharded x{world}" if world > 1 else "single GPU"},
         "recall_at_10": recall,
         "recall_sweep": sweep,

@@ -77,6 +77,14 @@ typedef enum cuddle_code_kind { CUDDLE_CODE_BINARY = 0, CUDDLE_CODE_RABITQ = 1 }
  *   ids[p] is the reference's vector index (usize) of that vector.
  * All per-vector arrays (ids, vectors, codes, rabitq_*) are given in leaf-contiguous order.
  * The library copies everything to the device at create time; the caller keeps ownership. */
+/* cuddle_index_desc.flags */
+/* centroids, ids, vectors, codes and the rabitq_* arrays are device pointers on the target device
+ * (the tree arrays child_offsets / children / roots / vec_offsets are always host pointers). */
+#define CUDDLE_DESC_DEVICE_ARRAYS 0x1u
+/* with DEVICE_ARRAYS: use `vectors` and `ids` in place instead of copying them; the caller keeps
+ * them alive and unchanged until cuddle_index_destroy (a 64 GB shard is then held once, not twice). */
+#define CUDDLE_DESC_ADOPT_VECTORS 0x2u
+
 typedef struct cuddle_index_desc {
     uint32_t abi_version;  /* CUDDLE_ABI_VERSION */
     uint32_t dim;          /* D */
@@ -96,7 +104,7 @@ typedef struct cuddle_index_desc {
      * vector at word i/64, bit i%64 (binary.rs:150-155); threshold = BinaryQuantizer::threshold */
     const uint64_t *codes;          /* [n_vectors][ceil(dim/64)] or NULL for RABITQ */
     float threshold;
-    uint32_t reserved0;
+    uint32_t flags;                 /* CUDDLE_DESC_* */
     /* RaBitQ: rotation_matrix_t rows (rabitq.rs:20), RaBitQVector fields (:24-32) */
     const float *rabitq_rot_t;      /* [dim][dim] or NULL */
     const uint32_t *rabitq_codes;   /* [n_vectors][ceil(dim/32)] */

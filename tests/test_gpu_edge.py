@@ -177,3 +177,20 @@ def test_device_pointer_entry_point_matches_host_one(gpu):
     assert np.array_equal(tid.cpu().numpy().view(np.uint64), ids) and np.array_equal(tdist.cpu().numpy(), dist)
     t = dev.stage_times()
     assert t["searches"] == 1 and t["scan"] > 0.0
+
+
+def test_device_array_index_matches_oracle(gpu):
+    """Index built on the GPU and adopted in place (no host copy) gives the oracle's answers."""
+    import torch
+    from vectordb_amd.synthetic import build_tree_index_on_device
+
+    orc = _oracle()
+    dti, q = build_tree_index_on_device(dim=32, fanout=6, levels=3, leaf_size=40, device="cuda:0", seed=3, n_queries=50)
+    dev = dti.create(gpu)
+    fi = dti.to_flat()
+    assert fi.n_vectors == 6 ** 3 * 40
+    ids, dist, cnt = dev.search_batch(q.cpu().numpy(), 10, 4, 6)
+    oi = orc.OracleIndex(fi)
+    for i in range(q.shape[0]):
+        r = oi.search(q[i].cpu().numpy(), 10, 4, 6)
+        assert np.array_equal(ids[i], r["ids"]) and np.array_equal(dist[i].view(np.uint32), r["dist"].view(np.uint32)), i

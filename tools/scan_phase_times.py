@@ -1,0 +1,69 @@
+"""Per-phase timing of the Hamming scan kernel's blocks (needs a -DCUDDLE_SCAN_TIMING build of the
+library, selected with CUDDLE_HIP_LIB). Prints the mean duration of each phase of a block and the
+average number of blocks in flight. Development tool; not used by the tests or the benchmark.
+
+    hipcc ... -DCUDDLE_SCAN_TIMING -o vectordb_amd/libcuddle_timing.so vectordb_amd/csrc/cuddle_hip.hip
+    CUDDLE_HIP_LIB=$PWD/vectordb_amd/libcuddle_timing.so python tools/scan_phase_times.py shard12m
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from vectordb_amd import _ffi  # noqa: E402
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "shard12m"
+    rf = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+    cfg = bench.CONFIGS[name]
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    if "tree" in cfg:
+        from vectordb_amd.synthetic import build_tree_index_on_device
+        fanout, levels, leaf = cfg["tree"]
+        dti, queries = build_tree_index_on_device(cfg["dim"], fanout, levels, leaf, device, seed=0xC0DD1E,
+                                                  n_queries=cfg["n_queries"])
+        idx = dti.create(0)
+    else:
+        from vectordb_amd.builder import build_index
+        from vectordb_amd.datasets import synthetic_mixture
+        from vectordb_amd.index import DeviceIndex
+        base, queries = synthetic_mixture(cfg["n"], cfg["dim"], seed=0xC0DD1E, device=device, style=cfg["style"],
+                                          n_queries=cfg["n_queries"], latent_dim=cfg["latent_dim"])
+        fi = build_index(base, cfg["branching"], cfg["leaf"], cfg["metric"], 20, seed=1, code_kind=cfg["code_kind"],
+                         threshold="mean")
+        idx = DeviceIndex(fi, 0)
+    nq, k = queries.shape[0], cfg["k"]
+    ids = torch.empty((nq, k), dtype=torch.int64, device=device)
+    dd = torch.empty((nq, k), dtype=torch.float32, device=device)
+    cnt = torch.empty((nq,), dtype=torch.int32, device=device)
+    for _ in range(3):
+        idx.search_batch_device(queries, k, cfg["probes"], rf, 0, ids, dd, cnt)
+    torch.cuda.synchronize()
+    lib = _ffi.lib()
+    fn = lib.cuddle_debug_scan_times
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+    fn.restype = ctypes.c_int
+    n = min(nq, 4096)
+    out = np.zeros((n, 8), dtype=np.uint64)
+    assert fn(out.ctypes.data, n) == 0
+    t = out[:, :5].astype(np.int64)
+    t = t[(t[:, 4] > 0)]
+    d = np.diff(t, axis=1) * 0.01  # 100 MHz ticks -> microseconds
+    names = ["prologue (leaf tables)", "phase 1 (stream codes)", "phase 2 (threshold)", "phase 3 (compaction)"]
+    for i, nm in enumerate(names):
+        print(f"{nm:28s} mean {d[:, i].mean():8.2f} us   p50 {np.median(d[:, i]):8.2f}   max {d[:, i].max():8.2f}")
+    life = (t[:, 4] - t[:, 0]) * 0.01
+    span = (t[:, 4].max() - t[:, 0].min()) * 0.01
+    print(f"block lifetime mean {life.mean():.2f} us; kernel span {span:.1f} us; blocks in flight (avg) "
+          f"{life.sum() / span:.1f} of {len(t)}")
+
+
+if __name__ == "__main__":
+    main()

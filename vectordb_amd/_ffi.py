@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcuddle_hip.so")
+# CUDDLE_HIP_LIB selects another build of the same library (kernel tuning experiments).
+LIB_PATH = os.environ.get("CUDDLE_HIP_LIB") or os.path.join(_HERE, "libcuddle_hip.so")
 
 ABI_VERSION = 1
 
@@ -33,6 +34,8 @@ CODE_BINARY, CODE_RABITQ = 0, 1
 SEARCH_STATS_VARIANT = 0x1
 SEARCH_TIME_STAGES = 0x2
 SEARCH_ROUTE_EXACT_ONLY = 0x4
+DESC_DEVICE_ARRAYS = 0x1
+DESC_ADOPT_VECTORS = 0x2
 STAGE_NAMES = ("quantize", "route", "scan", "rerank", "topk")
 
 
@@ -62,7 +65,7 @@ class IndexDesc(C.Structure):
         ("vectors", C.c_void_p),
         ("codes", C.c_void_p),
         ("threshold", C.c_float),
-        ("reserved0", C.c_uint32),
+        ("flags", C.c_uint32),
         ("rabitq_rot_t", C.c_void_p),
         ("rabitq_codes", C.c_void_p),
         ("rabitq_norm", C.c_void_p),

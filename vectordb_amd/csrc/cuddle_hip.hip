@@ -104,6 +104,7 @@ struct Plan {
     uint32_t sstride = 0;   // selection capacity per query
     uint32_t dist_cap = 0;  // candidates kept in LDS by the scan kernel
     uint32_t tcap = 0;      // 64-vector tiles per query (scan kernel)
+    uint32_t scan_threads = 512; // block size of the scan kernels
     size_t scan_lds = 0;
     // carved pointers
     uint64_t *qcodes = nullptr;
@@ -168,6 +169,24 @@ static constexpr uint32_t kScanThreads = 512;
 static constexpr uint32_t kGemmMinWidth = 512; // narrower levels are routed by the exact kernel
 static constexpr uint32_t kLdsDistCap = 24576; // u16 distances kept in LDS per query (48 KiB)
 
+using ScanKernel = void (*)(IndexDev, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, uint32_t,
+                            uint32_t, uint32_t, void *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *,
+                            const uint32_t *);
+
+// The Hamming scan instantiation for a code of `words` u64 (distances in u8 when dim < 255).
+static ScanKernel scan_kernel_for(uint32_t dim, uint32_t words) {
+    switch (words) {
+    case 2: return dim < 255 ? scan_select_hamming_kernel<uint8_t, 1, false, 16> : scan_select_hamming_kernel<uint16_t, 1, false, 16>;
+    case 4: return dim < 255 ? scan_select_hamming_kernel<uint8_t, 2, false, 8> : scan_select_hamming_kernel<uint16_t, 2, false, 8>;
+    case 8: return scan_select_hamming_kernel<uint16_t, 4, false, 4>;   // 512-d
+    case 12: return scan_select_hamming_kernel<uint16_t, 6, false, 2>;  // 768-d
+    case 15: return scan_select_hamming_kernel<uint16_t, 7, true, 2>;   // 960-d
+    case 16: return scan_select_hamming_kernel<uint16_t, 8, false, 2>;  // 1024-d
+    case 24: return scan_select_hamming_kernel<uint16_t, 12, false, 1>; // 1536-d
+    default: return dim < 255 ? scan_select_hamming_kernel<uint8_t, 0, false, 1> : scan_select_hamming_kernel<uint16_t, 0, false, 1>;
+    }
+}
+
 template <class T>
 static cuddle_status upload(cuddle_index *ix, const T *src, size_t count, T **dst) {
     *dst = nullptr;
@@ -177,7 +196,7 @@ static cuddle_status upload(cuddle_index *ix, const T *src, size_t count, T **ds
     if (e != hipSuccess) return fail(CUDDLE_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     ix->owned.push_back(p);
     ix->index_bytes += bytes;
-    if (count) HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    if (count) HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyDefault)); // host or device source
     *dst = static_cast<T *>(p);
     return CUDDLE_OK;
 }
@@ -323,7 +342,9 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     v.n_nodes = n; v.n_roots = d->n_roots; v.n_vectors = N;
 
     // host-side derived arrays
-    std::vector<uint32_t> vec_off32(n + 1), code_off(n, 0), pos_leaf(N);
+    std::vector<uint32_t> vec_off32(n + 1), code_off(n, 0);
+    const bool dev_arrays = (d->flags & CUDDLE_DESC_DEVICE_ARRAYS) != 0;
+    const bool adopt = dev_arrays && (d->flags & CUDDLE_DESC_ADOPT_VECTORS) != 0;
     uint64_t code_units = 0; // 16-byte units
     for (uint32_t i = 0; i <= n; ++i) vec_off32[i] = (uint32_t)d->vec_offsets[i];
     for (uint32_t i = 0; i < n; ++i) {
@@ -337,7 +358,6 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
         code_off[i] = (uint32_t)code_units;
         code_units += (uint64_t)(W / 2) * cnt + ((W & 1) ? (cnt + 1) / 2 : 0);
         if (code_units >= (1ull << 32)) return fail(CUDDLE_ERR_UNSUPPORTED, "binary codes exceed 64 GiB per shard");
-        for (uint32_t p = vec_off32[i]; p < vec_off32[i + 1]; ++p) pos_leaf[p] = i;
     }
 
     float *centroids; uint32_t *child_off, *children, *roots, *vec_off, *coff; uint64_t *ids; float *vectors;
@@ -347,8 +367,13 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     ST_TRY(upload(ix, d->roots, (size_t)d->n_roots, &roots));
     ST_TRY(upload(ix, vec_off32.data(), (size_t)n + 1, &vec_off));
     ST_TRY(upload(ix, code_off.data(), (size_t)n, &coff));
-    ST_TRY(upload(ix, d->ids, (size_t)N, &ids));
-    ST_TRY(upload(ix, d->vectors, (size_t)N * D, &vectors));
+    if (adopt) { // used in place; the caller keeps them alive
+        ids = const_cast<uint64_t *>(d->ids);
+        vectors = const_cast<float *>(d->vectors);
+    } else {
+        ST_TRY(upload(ix, d->ids, (size_t)N, &ids));
+        ST_TRY(upload(ix, d->vectors, (size_t)N * D, &vectors));
+    }
     v.centroids = centroids; v.child_off = child_off; v.children = children; v.roots = roots;
     v.vec_off = vec_off; v.code_off = coff; v.ids = ids; v.vectors = vectors;
 
@@ -370,14 +395,18 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
             const std::vector<uint32_t> &nodes = level_nodes[l];
             if (nodes.size() < kGemmMinWidth) continue;
             LevelGemm &g = ix->lvl[l];
-            std::vector<float> mu(D, 0.f);
-            if (d->metric == CUDDLE_METRIC_L2) {
-                std::vector<double> acc(D, 0.0);
-                for (uint32_t v2 : nodes)
-                    for (uint32_t i = 0; i < D; ++i) acc[i] += d->centroids[(size_t)v2 * D + i];
-                for (uint32_t i = 0; i < D; ++i) mu[i] = (float)(acc[i] / (double)nodes.size());
+            ST_TRY(dev_alloc(ix, (size_t)D, &g.mu));
+            HIP_TRY(hipMemset(g.mu, 0, D * sizeof(float)));
+            if (d->metric == CUDDLE_METRIC_L2) { // mu = mean centroid of the level, accumulated in double on the device
+                double *acc = nullptr;
+                HIP_TRY(hipMalloc((void **)&acc, D * sizeof(double)));
+                (void)hipMemset(acc, 0, D * sizeof(double));
+                hipLaunchKernelGGL(level_sum_kernel, dim3((D + 63) / 64, 256), dim3(64), 0, 0, centroids, g.nodes,
+                                   (uint32_t)nodes.size(), D, acc);
+                hipLaunchKernelGGL(level_mean_kernel, dim3((D + 255) / 256), dim3(256), 0, 0, acc, (uint32_t)nodes.size(), D, g.mu);
+                (void)hipDeviceSynchronize();
+                (void)hipFree(acc);
             }
-            ST_TRY(upload(ix, mu.data(), (size_t)D, &g.mu));
             ST_TRY(dev_alloc(ix, nodes.size() * (size_t)D, &g.table));
             ST_TRY(dev_alloc(ix, nodes.size(), &g.sqn));
             hipLaunchKernelGGL(level_table_kernel, dim3(((uint32_t)nodes.size() + 127) / 128), dim3(128), 0, 0, centroids,
@@ -392,23 +421,26 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     uint32_t *d_pos_leaf = nullptr;
     if (N) {
         HIP_TRY(hipMalloc((void **)&d_pos_leaf, N * sizeof(uint32_t)));
-        hipError_t e = hipMemcpy(d_pos_leaf, pos_leaf.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(d_pos_leaf); return fail(CUDDLE_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e)); }
+        hipLaunchKernelGGL(pos_leaf_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, vec_off, n, N, d_pos_leaf);
     }
     cuddle_status st = CUDDLE_OK;
     if (d->code_kind == CUDDLE_CODE_BINARY) {
         uint64_t *planar = nullptr, *raw = nullptr;
         st = dev_alloc(ix, (size_t)code_units * 2, &planar);
         if (st == CUDDLE_OK && N) {
-            hipError_t e = hipMalloc((void **)&raw, N * W * sizeof(uint64_t));
-            if (e != hipSuccess) st = fail(CUDDLE_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e));
-            if (st == CUDDLE_OK) {
-                (void)hipMemset(planar, 0, (size_t)code_units * 16);
-                e = hipMemcpy(raw, d->codes, N * W * sizeof(uint64_t), hipMemcpyHostToDevice);
-                if (e != hipSuccess) st = fail(CUDDLE_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+            const uint64_t *src = d->codes; // device arrays are re-laid straight from the caller's buffer
+            (void)hipMemset(planar, 0, (size_t)code_units * 16);
+            if (!dev_arrays) {
+                hipError_t e = hipMalloc((void **)&raw, N * W * sizeof(uint64_t));
+                if (e != hipSuccess) st = fail(CUDDLE_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e));
+                if (st == CUDDLE_OK) {
+                    e = hipMemcpy(raw, d->codes, N * W * sizeof(uint64_t), hipMemcpyHostToDevice);
+                    if (e != hipSuccess) st = fail(CUDDLE_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+                }
+                src = raw;
             }
             if (st == CUDDLE_OK)
-                hipLaunchKernelGGL(relayout_codes_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, raw, planar,
+                hipLaunchKernelGGL(relayout_codes_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, src, planar,
                                    vec_off, coff, d_pos_leaf, N, W);
             (void)hipDeviceSynchronize();
             if (raw) (void)hipFree(raw);
@@ -424,14 +456,18 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
         if (st == CUDDLE_OK) st = upload(ix, d->rabitq_ip_oo, (size_t)N, &ipoo);
         if (st == CUDDLE_OK) st = dev_alloc(ix, (size_t)N * W32, &rc);
         if (st == CUDDLE_OK && N) {
-            hipError_t e = hipMalloc((void **)&raw, N * W32 * sizeof(uint32_t));
-            if (e != hipSuccess) st = fail(CUDDLE_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e));
-            if (st == CUDDLE_OK) {
-                e = hipMemcpy(raw, d->rabitq_codes, N * W32 * sizeof(uint32_t), hipMemcpyHostToDevice);
-                if (e != hipSuccess) st = fail(CUDDLE_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+            const uint32_t *src = d->rabitq_codes;
+            if (!dev_arrays) {
+                hipError_t e = hipMalloc((void **)&raw, N * W32 * sizeof(uint32_t));
+                if (e != hipSuccess) st = fail(CUDDLE_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e));
+                if (st == CUDDLE_OK) {
+                    e = hipMemcpy(raw, d->rabitq_codes, N * W32 * sizeof(uint32_t), hipMemcpyHostToDevice);
+                    if (e != hipSuccess) st = fail(CUDDLE_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+                }
+                src = raw;
             }
             if (st == CUDDLE_OK)
-                hipLaunchKernelGGL(relayout_rabitq_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, raw, rc,
+                hipLaunchKernelGGL(relayout_rabitq_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, src, rc,
                                    vec_off, d_pos_leaf, N, W32);
             (void)hipDeviceSynchronize();
             if (raw) (void)hipFree(raw);
@@ -447,7 +483,7 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     // kernels that may need more than 64 KiB of dynamic LDS
     (void)hipFuncSetAttribute((const void *)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)selection_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)scan_select_hamming_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)scan_kernel_for(v.dim, v.words), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_all_hamming_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -512,18 +548,22 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
         fb = std::min<uint64_t>(fb, width);
         fmax = std::max(fmax, fb);
         uint64_t sel = std::min<uint64_t>(fb, probes);
-        lsum += sel;
+        lsum += std::min<uint64_t>(sel, ix->level_leaves[l]); // a level contributes at most its own leaves
         fb = sel * std::max<uint32_t>(ix->max_children, 1);
     }
     pl.fstride = (uint32_t)align_up(fmax, 4);
     pl.lstride = (uint32_t)align_up(std::max<uint64_t>(std::min<uint64_t>(lsum, ix->n_leaves), std::max<uint32_t>(lstride_min, 1)), 4);
     uint64_t cbound = std::min<uint64_t>((uint64_t)pl.lstride * ix->max_leaf, v.n_vectors);
-    pl.cstride = (uint32_t)align_up(std::max<uint64_t>(cbound, 8), 8);
+    pl.cstride = (uint32_t)align_up(std::max<uint64_t>(cbound, 8), 128); // spill rows never share a cache line
     pl.sstride = (uint32_t)align_up(std::max<uint64_t>(std::min<uint64_t>(pl.rerank_k, cbound), 4), 4);
     pl.tcap = (uint32_t)align_up((size_t)pl.lstride + pl.cstride / 64 + 1, 4);
+    // small per-query scans (few candidates): smaller blocks, more of them per CU, so that the
+    // latency-bound prologue/selection phases of one query overlap the streaming of others
+    pl.scan_threads = pl.cstride <= 16384 ? 256 : kScanThreads;
     if (v.code_kind == CUDDLE_CODE_BINARY) {
-        pl.dist_cap = std::min(pl.cstride, kLdsDistCap);
-        pl.scan_lds = scan_lds_bytes(v.dim, v.words, pl.lstride, pl.tcap, pl.dist_cap);
+        const uint32_t esz = v.dim < 255 ? 1 : 2; // one byte per distance when dim < 255
+        pl.dist_cap = std::min<uint32_t>(pl.cstride, kLdsDistCap * 2 / esz);
+        pl.scan_lds = scan_lds_bytes(v.dim, v.words, pl.lstride, pl.tcap, (pl.dist_cap * esz + 1) / 2, v.words == 2);
     } else {
         pl.dist_cap = std::min(pl.cstride, kLdsDistCap / 2); // f32 estimates
         pl.scan_lds = rabitq_scan_lds_bytes(v.dim, pl.lstride, pl.tcap, pl.dist_cap);
@@ -538,7 +578,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     size_t o_fc0 = carve(qc * 4), o_fc1 = carve(qc * 4);
     size_t o_fd = carve(qc * pl.fstride * 4);
     size_t o_lv = carve(qc * pl.lstride * 4), o_lc = carve(qc * 4);
-    size_t o_gd = carve(qc * (size_t)pl.cstride * 4); // u16 Hamming or f32 estimates
+    size_t o_gd = carve(qc * (size_t)pl.cstride * 4); // u8/u16 Hamming or f32 estimates
     size_t o_sp = carve(qc * pl.sstride * 4), o_sk = carve(qc * pl.sstride * 4), o_sd = carve(qc * pl.sstride * 4);
     size_t o_sc = carve(qc * 4), o_cc = carve(qc * 4);
     pl.kc_cap = (uint32_t)align_up((size_t)pl.probes + route_margin(pl.probes), 32);
@@ -681,17 +721,27 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
     return CUDDLE_OK;
 }
 
+#ifdef CUDDLE_SCAN_TIMING
+static void *g_scan_stamps = nullptr;
+extern "C" int cuddle_debug_scan_times(uint64_t *out, uint32_t nq) {
+    if (!g_scan_stamps) return 1;
+    return (int)hipMemcpy(out, g_scan_stamps, (size_t)nq * 64, hipMemcpyDeviceToHost);
+}
+#endif
+
 // Scan + phase-1 selection for the leaf lists in pl.leaves / pl.lcount.
 static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32_t nq, hipStream_t s) {
     const IndexDev &v = ix->dev;
+#ifdef CUDDLE_SCAN_TIMING
+    g_scan_stamps = pl.gdist;
+#endif
     // longest queries first (nq <= kMaxChunk = 4096 fits one sorting block)
     hipLaunchKernelGGL(cand_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, pl.leaves, pl.lstride, pl.lcount, nq,
                        pl.cand_count);
-    hipLaunchKernelGGL(order_by_work_kernel, dim3(1), dim3(1024), (size_t)host_next_pow2(nq) * 8, s, pl.cand_count, nq,
-                       pl.order);
+    hipLaunchKernelGGL(order_by_work_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, pl.cand_count, nq, pl.order);
     if (v.code_kind == CUDDLE_CODE_RABITQ) {
         const float *rq = reinterpret_cast<const float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
-        hipLaunchKernelGGL(scan_select_rabitq_kernel, dim3(nq), dim3(kScanThreads), pl.scan_lds, s, v, rq, qn, pl.leaves,
+        hipLaunchKernelGGL(scan_select_rabitq_kernel, dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, rq, qn, pl.leaves,
                            pl.lstride, pl.lcount, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap,
                            reinterpret_cast<float *>(pl.gdist), pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count,
                            pl.cand_count, pl.order);
@@ -700,9 +750,9 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
         HIP_TRY(hipGetLastError());
         return CUDDLE_OK;
     }
-    hipLaunchKernelGGL(scan_select_hamming_kernel, dim3(nq), dim3(kScanThreads), pl.scan_lds, s, v, pl.qcodes, pl.leaves,
-                       pl.lstride, pl.lcount, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, pl.gdist, pl.cstride, pl.sel_pos,
-                       pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, pl.order);
+    hipLaunchKernelGGL(scan_kernel_for(v.dim, v.words), dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, pl.qcodes,
+                       pl.leaves, pl.lstride, pl.lcount, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, (void *)pl.gdist,
+                       pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, pl.order);
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
 }

@@ -120,22 +120,35 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t v) {
 
 // Ordered threshold compaction. Over items i in [0, C) with integer keys key(i), emit every item
 // with key < T and the first `budget` items (in index order) with key == T, calling
-// emit(i, key, rank) with rank = the item's position among the emitted ones in index order.
+// emit(i, key, aux, rank) with rank = the item's position among the emitted ones in index order
+// and aux = whatever key(i, aux) stored for the item.
 // Each wave owns one contiguous segment; wtmp needs 2 * (blockDim.x / 64) u32 of LDS.
 // All threads of the block call; contains two barriers.
 template <class KeyFn, class EmitFn>
-__device__ __forceinline__ void ordered_threshold_compact(uint32_t C, uint32_t T, uint32_t budget,
+__device__ __forceinline__ void ordered_threshold_compact_aux(uint32_t C, uint32_t T, uint32_t budget,
                                                           KeyFn key, EmitFn emit, uint32_t *wtmp) {
     const uint32_t nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t seg = (C + nw - 1) / nw;
     seg = (seg + 63) & ~63u;
     const uint32_t beg = min(w * seg, C), end = min(beg + seg, C);
+    // Both passes read four 64-element steps at a time so that the key loads of a step do not wait
+    // for the ballots of the one before. key(i, aux) may hand a per-element value on to emit.
+    constexpr int kSteps = 4;
     uint32_t n_lt = 0, n_tie = 0;
-    for (uint32_t i0 = beg; i0 < end; i0 += 64) {
-        uint32_t i = i0 + lane;
-        uint32_t kv = (i < end) ? key(i) : 0xFFFFFFFFu;
-        n_lt += __popcll(__ballot(i < end && kv < T));
-        n_tie += __popcll(__ballot(i < end && kv == T));
+    for (uint32_t i0 = beg; i0 < end; i0 += 64 * kSteps) {
+        uint32_t kv[kSteps];
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u) {
+            const uint32_t i = i0 + 64 * u + lane;
+            uint32_t aux;
+            kv[u] = (i < end) ? key(i, aux) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u) {
+            const bool in = i0 + 64 * u + lane < end;
+            n_lt += __popcll(__ballot(in && kv[u] < T));
+            n_tie += __popcll(__ballot(in && kv[u] == T));
+        }
     }
     if (lane == 0) {
         wtmp[w] = n_lt;
@@ -149,18 +162,141 @@ __device__ __forceinline__ void ordered_threshold_compact(uint32_t C, uint32_t T
     }
     uint32_t out_before = lt_before + min(tie_before, budget);
     const uint64_t lm = lanemask_lt();
-    for (uint32_t i0 = beg; i0 < end; i0 += 64) {
-        uint32_t i = i0 + lane;
-        bool in = i < end;
-        uint32_t kv = in ? key(i) : 0xFFFFFFFFu;
-        bool tie = in && kv == T;
-        uint64_t tb = __ballot(tie);
-        uint32_t tie_rank = tie_before + __popcll(tb & lm);
-        bool flag = in && (kv < T || (tie && tie_rank < budget));
-        uint64_t fb = __ballot(flag);
-        if (flag) emit(i, kv, out_before + (uint32_t)__popcll(fb & lm));
-        tie_before += __popcll(tb);
-        out_before += __popcll(fb);
+    for (uint32_t i0 = beg; i0 < end; i0 += 64 * kSteps) {
+        uint32_t kv[kSteps], aux[kSteps];
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u) {
+            const uint32_t i = i0 + 64 * u + lane;
+            aux[u] = 0;
+            kv[u] = (i < end) ? key(i, aux[u]) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u) {
+            const uint32_t i = i0 + 64 * u + lane;
+            const bool in = i < end;
+            const bool tie = in && kv[u] == T;
+            const uint64_t tb = __ballot(tie);
+            const uint32_t tie_rank = tie_before + __popcll(tb & lm);
+            const bool flag = in && (kv[u] < T || (tie && tie_rank < budget));
+            const uint64_t fb = __ballot(flag);
+            if (flag) emit(i, kv[u], aux[u], out_before + (uint32_t)__popcll(fb & lm));
+            tie_before += __popcll(tb);
+            out_before += __popcll(fb);
+        }
+    }
+    __syncthreads();
+}
+
+// The same with key(i) and emit(i, key, rank).
+template <class KeyFn, class EmitFn>
+__device__ __forceinline__ void ordered_threshold_compact(uint32_t C, uint32_t T, uint32_t budget, KeyFn key, EmitFn emit,
+                                                          uint32_t *wtmp) {
+    ordered_threshold_compact_aux(
+        C, T, budget, [&](uint32_t i, uint32_t &) -> uint32_t { return key(i); },
+        [&](uint32_t i, uint32_t kv, uint32_t, uint32_t rank) { emit(i, kv, rank); }, wtmp);
+}
+
+// Ordered threshold selection over packed small keys (DistT = u8 or u16, `dist` 4-byte aligned and
+// readable up to the next multiple of 4 bytes): the same result as ordered_threshold_compact, but
+// every lane walks its own contiguous run of 32-bit words, so the loop body has no cross-lane
+// operation: pass 1 counts keys < T and == T per lane, one wave scan and a per-wave table turn the
+// counts into each lane's starting ranks, pass 2 calls emit(i, key, rank) for the selected items.
+// The words of a lane are an odd number apart from the next lane's (no LDS bank conflicts).
+// Keys are compared a word at a time: for fields of B bits and n <= 2^(B-1),
+// ((L + n * ONES) - (x & L)) & ~x & H has a field's top bit set exactly when the field is < n
+// (H = the top bit of every field, L = ~H; neither the sum nor the difference crosses a field).
+// When T + 1 > 2^(B-1) the fields are compared one by one instead.
+// wtmp needs 2 * (blockDim.x / 64) u32. All threads call; contains two barriers.
+template <class DistT, class EmitFn>
+__device__ __forceinline__ void chunked_threshold_select(const DistT *dist, uint32_t C, uint32_t T, uint32_t budget,
+                                                         EmitFn emit, uint32_t *wtmp) {
+    constexpr uint32_t EPW = 4 / sizeof(DistT), BITS = 8 * sizeof(DistT), MASK = (1u << BITS) - 1;
+    constexpr uint32_t H = BITS == 8 ? 0x80808080u : 0x80008000u, L = ~H, ONES = BITS == 8 ? 0x01010101u : 0x00010001u;
+    const uint32_t nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(dist);
+    const uint32_t nwords = (C + EPW - 1) / EPW;
+    const uint32_t mw = (((nwords + nw - 1) / nw + 63) / 64) | 1u; // words per lane, odd
+    const uint32_t wb = min((w * 64 + lane) * mw, nwords), we = min(wb + mw, nwords);
+    // fields past the last key read as all ones: never < T, never == T (T <= dim + 1 < all ones)
+    const uint32_t tail_valid = C - (nwords - 1) * EPW;
+    const uint32_t tail_or = tail_valid < EPW ? ~0u << (tail_valid * BITS) : 0u;
+    auto load = [&](uint32_t j) -> uint32_t {
+        if (j >= we) return 0xFFFFFFFFu;
+        const uint32_t x = words[j];
+        return j == nwords - 1 ? x | tail_or : x;
+    };
+    const bool swar = T + 1 <= (1u << (BITS - 1));
+    const uint32_t a_lt = L + T * ONES, a_le = L + (T + 1) * ONES; // used when swar
+    uint32_t n_lt = 0, n_tie = 0;
+    for (uint32_t j0 = wb; j0 < we; j0 += 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = load(j0 + u);
+        if (swar) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t lo = v[u] & L, nx = ~v[u] & H;
+                const uint32_t lt = (a_lt - lo) & nx, le = (a_le - lo) & nx;
+                n_lt += __popc(lt);
+                n_tie += __popc(le ^ lt);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (uint32_t e = 0; e < EPW; ++e) {
+                    const uint32_t kv = (v[u] >> (e * BITS)) & MASK;
+                    n_lt += kv < T ? 1u : 0u;
+                    n_tie += kv == T ? 1u : 0u;
+                }
+            }
+        }
+    }
+    const uint32_t incl_lt = wave_inclusive_sum(n_lt), incl_tie = wave_inclusive_sum(n_tie);
+    if (lane == 63) {
+        wtmp[w] = incl_lt;
+        wtmp[nw + w] = incl_tie;
+    }
+    __syncthreads();
+    uint32_t lt_run = incl_lt - n_lt, tie_run = incl_tie - n_tie;
+    for (uint32_t v = 0; v < w; ++v) {
+        lt_run += wtmp[v];
+        tie_run += wtmp[nw + v];
+    }
+    for (uint32_t j0 = wb; j0 < we; j0 += 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = load(j0 + u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (swar) {
+                const uint32_t lo = v[u] & L, nx = ~v[u] & H;
+                const uint32_t lt = (a_lt - lo) & nx, tie = ((a_le - lo) & nx) ^ lt;
+                // ties stop mattering to this lane once the budget is used up before it
+                uint32_t m = lt | (tie_run < budget ? tie : 0u);
+                while (m) {
+                    const uint32_t bit = __ffs(m) - 1, e = bit / BITS;
+                    const uint32_t kv = (v[u] >> (e * BITS)) & MASK, i = (j0 + u) * EPW + e;
+                    if ((lt >> bit) & 1u) {
+                        emit(i, kv, lt_run + min(tie_run, budget));
+                        ++lt_run;
+                    } else {
+                        if (tie_run < budget) emit(i, kv, lt_run + tie_run);
+                        ++tie_run;
+                    }
+                    m &= m - 1;
+                }
+            } else {
+#pragma unroll
+                for (uint32_t e = 0; e < EPW; ++e) {
+                    const uint32_t kv = (v[u] >> (e * BITS)) & MASK;
+                    const bool lt = kv < T, tie = kv == T;
+                    if (lt || (tie && tie_run < budget)) emit((j0 + u) * EPW + e, kv, lt_run + min(tie_run, budget));
+                    lt_run += lt ? 1u : 0u;
+                    tie_run += tie ? 1u : 0u;
+                }
+            }
+        }
     }
     __syncthreads();
 }
@@ -344,6 +480,32 @@ __global__ void hamming_pairs_kernel(const uint64_t *a, const uint64_t *b, uint6
 // index set-up kernels
 // ---------------------------------------------------------------------------------------------
 
+// pos_leaf[p] = node whose vector range contains leaf-contiguous position p (binary search in vec_off).
+__global__ void pos_leaf_kernel(const uint32_t *vec_off, uint32_t n_nodes, uint64_t n_vectors, uint32_t *pos_leaf) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_vectors) return;
+    uint32_t lo = 0, hi = n_nodes; // vec_off[lo] <= p < vec_off[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (vec_off[mid] <= p) lo = mid; else hi = mid;
+    }
+    pos_leaf[p] = lo;
+}
+
+// acc[i] += sum over this block's slice of the listed nodes of centroid[node][i] (double);
+// grid = (ceil(dim/64), slices), block = 64.
+__global__ void level_sum_kernel(const float *centroids, const uint32_t *nodes, uint32_t n, uint32_t dim, double *acc) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= dim) return;
+    double s = 0.0;
+    for (uint32_t j = blockIdx.y; j < n; j += gridDim.y) s += (double)centroids[(uint64_t)nodes[j] * dim + i];
+    atomicAdd(&acc[i], s);
+}
+__global__ void level_mean_kernel(const double *acc, uint32_t n, uint32_t dim, float *mu) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < dim) mu[i] = (float)(acc[i] / (double)n);
+}
+
 // Re-lay vector-major binary codes [n_vectors][words] into the per-leaf planar layout the scan
 // streams: for a leaf with n vectors starting at 16-byte unit code_off, plane p (p < words/2)
 // holds words (2p, 2p+1) of vector i at 16-byte slot p*n + i; when `words` is odd a last plane of
@@ -412,6 +574,8 @@ struct ScanLds {
     uint32_t *lscan;    // [lcap + 1]  exclusive prefix of leaf sizes = scan position of the leaf
     uint32_t *ltile;    // [lcap + 1]  exclusive prefix of the leaves' 64-vector tile counts
     uint32_t *tiles;    // [tcap]      (leaf slot << 12) | tile number inside the leaf
+    uint32_t *tinfo;    // [tcap]      (scan position of the tile's first vector << 7) | vectors in the tile
+    uint32_t *tcode;    // [tcap]      16-byte unit offset of the tile's first vector in plane 0 (optional)
     uint32_t *wtmp;     // [32]
     uint32_t *misc;     // [8]
     uint64_t *qw;       // [words]
@@ -421,7 +585,7 @@ struct ScanLds {
 __device__ __host__ __forceinline__ uint32_t scan_pad4(uint32_t v) { return (v + 3) & ~3u; }
 
 __device__ __forceinline__ ScanLds scan_lds_carve(unsigned char *smem, uint32_t dim, uint32_t words, uint32_t lcap,
-                                                  uint32_t tcap) {
+                                                  uint32_t tcap, bool with_tcode = false) {
     ScanLds s;
     uint32_t *p = reinterpret_cast<uint32_t *>(smem);
     s.hist = p; p += scan_pad4(dim + 2);
@@ -430,6 +594,8 @@ __device__ __forceinline__ ScanLds scan_lds_carve(unsigned char *smem, uint32_t 
     s.lscan = p; p += scan_pad4(lcap + 1);
     s.ltile = p; p += scan_pad4(lcap + 1);
     s.tiles = p; p += scan_pad4(tcap);
+    s.tinfo = p; p += scan_pad4(tcap);
+    s.tcode = with_tcode ? p : nullptr; p += with_tcode ? scan_pad4(tcap) : 0;
     s.wtmp = p; p += 32;
     s.misc = p; p += 8;
     s.qw = reinterpret_cast<uint64_t *>(p); p += 2 * ((words + 1) & ~1u);
@@ -437,8 +603,10 @@ __device__ __forceinline__ ScanLds scan_lds_carve(unsigned char *smem, uint32_t 
     return s;
 }
 
-inline size_t scan_lds_bytes(uint32_t dim, uint32_t words, uint32_t lcap, uint32_t tcap, uint32_t dist_cap) {
-    size_t u32s = scan_pad4(dim + 2) + 2 * (size_t)scan_pad4(lcap) + 2 * (size_t)scan_pad4(lcap + 1) + scan_pad4(tcap) + 32 +
+inline size_t scan_lds_bytes(uint32_t dim, uint32_t words, uint32_t lcap, uint32_t tcap, uint32_t dist_cap,
+                             bool with_tcode = false) {
+    size_t u32s = scan_pad4(dim + 2) + 2 * (size_t)scan_pad4(lcap) + 2 * (size_t)scan_pad4(lcap + 1) +
+                  (with_tcode ? 3 : 2) * (size_t)scan_pad4(tcap) + 32 +
                   8 + 2 * (size_t)((words + 1) & ~1u);
     return u32s * 4 + (size_t)dist_cap * 2;
 }
@@ -464,7 +632,13 @@ __device__ __forceinline__ uint32_t scan_load_leaves(const IndexDev &ix, const S
     if (tcap) {
         for (uint32_t t = threadIdx.x; t < nl; t += blockDim.x) {
             const uint32_t tb = s.ltile[t], te = s.ltile[t + 1];
-            for (uint32_t c = tb; c < te && c < tcap; ++c) s.tiles[c] = (t << 12) | (c - tb);
+            const uint32_t base = s.lscan[t], n = s.lscan[t + 1] - base;
+            for (uint32_t c = tb; c < te && c < tcap; ++c) {
+                const uint32_t first = (c - tb) << 6;
+                s.tiles[c] = (t << 12) | (c - tb);
+                s.tinfo[c] = ((base + first) << 7) | min(64u, n - first);
+                if (s.tcode) s.tcode[c] = s.lcode[t] + first;
+            }
         }
         __syncthreads();
     }
@@ -485,11 +659,35 @@ __device__ __forceinline__ uint32_t scan_slot_of(const uint32_t *lscan, uint32_t
 // Phase 1 of the scan for codes of 2*PAIRS (+1 if TAIL) words: each wave takes U tiles at a time
 // and issues all of their 128-bit loads (U * PAIRS per lane, every one a fully coalesced
 // wave-wide read of consecutive 16-byte slots) before the first XOR/popcount, so that one wave
-// keeps U * PAIRS KiB in flight.
-template <int PAIRS, bool TAIL, int U>
-__device__ __forceinline__ void scan_tiles(const IndexDev &ix, const ScanLds &s, uint32_t ntiles, bool use_lds,
-                                           uint16_t *gd) {
+// keeps U * PAIRS KiB in flight. Distances are stored by scan position.
+template <int PAIRS, bool TAIL, int U, class DistT>
+__device__ __forceinline__ void scan_tiles(const IndexDev &ix, const ScanLds &s, uint32_t ntiles, DistT *dist) {
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (PAIRS == 1 && !TAIL) {
+        // two-word codes: one 16-byte slot per vector, addressed through the per-tile tables alone
+        const uint64_t q0 = s.qw[0], q1 = s.qw[1];
+        for (uint32_t t0 = w * U; t0 < ntiles; t0 += nw * U) {
+            uint4 c[U];
+            uint32_t ti[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t t = t0 + u;
+                ti[u] = t < ntiles ? s.tinfo[t] : 0u;
+                const uint32_t co = s.tcode[t < ntiles ? t : t0];
+                c[u] = lane < (ti[u] & 127u) ? ix.codes[(uint64_t)co + lane] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t a = ((uint64_t)c[u].y << 32) | c[u].x, b = ((uint64_t)c[u].w << 32) | c[u].z;
+                const uint32_t h = __popcll(a ^ q0) + __popcll(b ^ q1);
+                if (lane < (ti[u] & 127u)) {
+                    dist[(ti[u] >> 7) + lane] = (DistT)h;
+                    atomicAdd(&s.hist[h], 1u);
+                }
+            }
+        }
+        return;
+    }
     for (uint32_t t0 = w * U; t0 < ntiles; t0 += nw * U) {
         uint4 c[U][PAIRS > 0 ? PAIRS : 1];
         uint2 ct[U];
@@ -521,7 +719,7 @@ __device__ __forceinline__ void scan_tiles(const IndexDev &ix, const ScanLds &s,
             }
             if (TAIL) h += __popcll((((uint64_t)ct[u].y << 32) | ct[u].x) ^ s.qw[2 * PAIRS]);
             if (act[u]) {
-                if (use_lds) s.dist[pos[u]] = (uint16_t)h; else gd[pos[u]] = (uint16_t)h;
+                dist[pos[u]] = (DistT)h;
                 atomicAdd(&s.hist[h], 1u);
             }
         }
@@ -545,40 +743,61 @@ cand_count_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const u
     if (lane == 0) cand_count[q] = c;
 }
 
-// order[i] = the query with the i-th most candidates. The scan kernels process queries in this
-// order so that the longest blocks start first and the tail of the launch is made of short ones.
-// One block, nq <= 4096; dynamic LDS = next_pow2(nq) u64.
-__global__ void __launch_bounds__(1024)
+// order[i] = the query with the i-th most candidates (ties by query number). The scan kernels
+// process queries in this order so that the longest blocks start first and the tail of the launch
+// is made of short ones. One wave per query counts the queries that precede it.
+__global__ void __launch_bounds__(256)
 order_by_work_kernel(const uint32_t *cand_count, uint32_t nq, uint32_t *order) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);
-    const uint32_t npad = next_pow2(max(nq, 1u));
-    for (uint32_t i = threadIdx.x; i < npad; i += blockDim.x)
-        skeys[i] = i < nq ? (((uint64_t)(~cand_count[i]) << 32) | i) : ~0ull;
-    __syncthreads();
-    block_bitonic_sort_u64(skeys, npad);
-    for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) order[i] = (uint32_t)skeys[i];
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const uint32_t mine = cand_count[q];
+    uint32_t before = 0;
+    for (uint32_t j = lane; j < nq; j += 64) {
+        const uint32_t c = cand_count[j];
+        before += (c > mine || (c == mine && j < q)) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if (lane == 0) order[before] = q;
 }
 
-// One block per query. Phase 1 streams the planar codes of every reached leaf (tiles of 64
-// vectors, lane = vector), XOR + popcount against the query code, and keeps each candidate's
-// Hamming distance as u16 (LDS when the query's candidates fit in dist_cap, else the global
-// spill buffer) while building a (dim+1)-bin histogram. Phase 2 turns the histogram into the
-// selection threshold: T = smallest h with #(<= h) >= rerank_k, budget = rerank_k - #(< T).
-// Phase 3 emits, in scan order, every candidate with h < T and the first `budget` with h == T:
-// the first rerank_k elements of the reference's stable sort_by_key (hierarchical.rs:646-648,
-// :930-932), i.e. a legal result of select_nth_unstable_by (:651), listed in scan order.
-// sel_pos / sel_key: [nq][sel_stride]; gdist: [nq][gdist_stride] u16 spill.
-__global__ void __launch_bounds__(512)
+// One block per query (queries taken in `order`, longest first). Phase 1 streams the planar codes
+// of every reached leaf (tiles of 64 vectors, lane = vector), XOR + popcount against the query
+// code, and keeps each candidate's Hamming distance (DistT = u8 when dim < 255, else u16; in LDS
+// when the query's candidates fit in dist_cap, else in the global spill buffer) while building a
+// (dim+1)-bin histogram. Phase 2 turns the histogram into the selection threshold: T = smallest h
+// with #(<= h) >= rerank_k, budget = rerank_k - #(< T). Phase 3 emits, in scan order, every
+// candidate with h < T and the first `budget` with h == T: the first rerank_k elements of the
+// reference's stable sort_by_key (hierarchical.rs:646-648, :930-932), i.e. a legal result of
+// select_nth_unstable_by (:651), listed in scan order.
+// sel_pos / sel_key: [nq][sel_stride]; gdist: [nq][gdist_stride] spill.
+// One instantiation per code width (PAIRS = 0: any width, generic loop) so that each gets its own
+// register allocation; gdist_v points at DistT elements.
+// Debug builds (-DCUDDLE_SCAN_TIMING) stamp the 100 MHz clock at the phase boundaries of every
+// block into the spill buffer (which such a run must not otherwise use).
+#ifdef CUDDLE_SCAN_TIMING
+#define CUDDLE_STAMP(n)                                                                                      \
+    do {                                                                                                     \
+        if (threadIdx.x == 0) reinterpret_cast<uint64_t *>(gdist_v)[(uint64_t)q * 8 + (n)] = wall_clock64(); \
+    } while (0)
+#else
+#define CUDDLE_STAMP(n) do { } while (0)
+#endif
+#ifndef CUDDLE_SCAN_WAVES
+#define CUDDLE_SCAN_WAVES 1
+#endif
+template <class DistT, int PAIRS, bool TAIL, int U>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(CUDDLE_SCAN_WAVES)))
 scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *leaves, uint32_t lstride,
                            const uint32_t *lcount, uint32_t lcap, uint32_t tcap, uint32_t rerank_k, uint32_t dist_cap,
-                           uint16_t *gdist, uint32_t gdist_stride, uint32_t *sel_pos, uint32_t *sel_key,
+                           void *gdist_v, uint32_t gdist_stride, uint32_t *sel_pos, uint32_t *sel_key,
                            uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count, const uint32_t *order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t q = order ? order[blockIdx.x] : blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const uint32_t D = ix.dim, W = ix.words;
-    ScanLds s = scan_lds_carve(smem, D, W, lcap, tcap);
+    ScanLds s = scan_lds_carve(smem, D, W, lcap, tcap, PAIRS == 1 && !TAIL);
+    CUDDLE_STAMP(0);
     const uint32_t nl = min(lcount[q], lcap);
     for (uint32_t i = tid; i < D + 2; i += blockDim.x) s.hist[i] = 0;
     for (uint32_t i = tid; i < W; i += blockDim.x) s.qw[i] = qcodes[(uint64_t)q * W + i];
@@ -589,29 +808,25 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
         if (tid == 0) sel_count[q] = 0;
         return;
     }
-    const bool use_lds = C <= dist_cap;
-    uint16_t *gd = gdist + (uint64_t)q * gdist_stride;
+    CUDDLE_STAMP(1);
+    DistT *dist = C <= dist_cap ? reinterpret_cast<DistT *>(s.dist)
+                                   : reinterpret_cast<DistT *>(gdist_v) + (uint64_t)q * gdist_stride;
     // phase 1
-    switch (W) {
-    case 2: scan_tiles<1, false, 8>(ix, s, ntiles, use_lds, gd); break;    // 128-d
-    case 4: scan_tiles<2, false, 8>(ix, s, ntiles, use_lds, gd); break;    // 256-d
-    case 8: scan_tiles<4, false, 4>(ix, s, ntiles, use_lds, gd); break;    // 512-d
-    case 12: scan_tiles<6, false, 2>(ix, s, ntiles, use_lds, gd); break;   // 768-d
-    case 15: scan_tiles<7, true, 2>(ix, s, ntiles, use_lds, gd); break;    // 960-d
-    case 16: scan_tiles<8, false, 2>(ix, s, ntiles, use_lds, gd); break;   // 1024-d
-    case 24: scan_tiles<12, false, 1>(ix, s, ntiles, use_lds, gd); break;  // 1536-d
-    default:
+    if (PAIRS > 0) {
+        scan_tiles<PAIRS, TAIL, U>(ix, s, ntiles, dist);
+    } else {
         for (uint32_t t = w; t < ntiles; t += nw) {
             const uint32_t tile = s.tiles[t], sl = tile >> 12, i = ((tile & 4095u) << 6) + lane;
             const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base;
             if (i < n) {
-                uint32_t h = leaf_hamming(ix.codes + s.lcode[sl], n, i, s.qw, W);
-                if (use_lds) s.dist[base + i] = (uint16_t)h; else gd[base + i] = (uint16_t)h;
+                const uint32_t h = leaf_hamming(ix.codes + s.lcode[sl], n, i, s.qw, W);
+                dist[base + i] = (DistT)h;
                 atomicAdd(&s.hist[h], 1u);
             }
         }
     }
     __syncthreads();
+    CUDDLE_STAMP(2);
     // phase 2
     uint32_t T, budget;
     if (C <= rerank_k) {
@@ -642,19 +857,34 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
         T = s.misc[0];
         budget = s.misc[1];
     }
-    // phase 3
+    CUDDLE_STAMP(3);
+    // phase 3: the selected scan positions are staged (in the tile tables, which phase 1 no longer
+    // needs, or in sel_pos itself when the selection is larger than those), then mapped to
+    // leaf-contiguous positions by all threads.
     uint32_t *sp = sel_pos + (uint64_t)q * sel_stride, *sk = sel_key + (uint64_t)q * sel_stride;
-    ordered_threshold_compact(
-        C, T, budget, [&](uint32_t i) -> uint32_t { return use_lds ? s.dist[i] : gd[i]; },
-        [&](uint32_t i, uint32_t kv, uint32_t rank) {
-            if (rank < sel_stride) {
-                uint32_t sl = scan_slot_of(s.lscan, nl, i);
-                sp[rank] = s.lbeg[sl] + (i - s.lscan[sl]);
-                sk[rank] = kv;
+    const uint32_t nsel = min(min(C, rerank_k), sel_stride);
+    uint32_t *stg = s.tiles;
+    const bool stage_lds = nsel <= ((PAIRS == 1 && !TAIL) ? 3u : 2u) * scan_pad4(tcap);
+    chunked_threshold_select(
+        dist, C, T, budget,
+        [&](uint32_t i, uint32_t, uint32_t rank) {
+            if (rank < nsel) {
+                if (stage_lds) stg[rank] = i; else sp[rank] = i;
             }
         },
         s.wtmp);
-    if (tid == 0) sel_count[q] = min(min(C, rerank_k), sel_stride);
+    if (!stage_lds) {
+        __threadfence();
+        __syncthreads();
+    }
+    for (uint32_t r = tid; r < nsel; r += blockDim.x) {
+        const uint32_t i = stage_lds ? stg[r] : __hip_atomic_load(sp + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t sl = scan_slot_of(s.lscan, nl, i);
+        sp[r] = s.lbeg[sl] + (i - s.lscan[sl]);
+        sk[r] = dist[i];
+    }
+    CUDDLE_STAMP(4);
+    if (tid == 0) sel_count[q] = nsel;
 }
 
 // collect_leaf_candidates (hierarchical.rs:618-641) written out in full: every candidate's

@@ -154,11 +154,12 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
     }
     __syncthreads();
     auto key = [&](uint32_t i) -> uint32_t { return f32_key(use_lds ? r.est[i] : ge[i]); };
+    auto key2 = [&](uint32_t i, uint32_t &) -> uint32_t { return key(i); };
     uint32_t T = 0xFFFFFFFFu, budget = 0;
     bool all = C <= rerank_k;
     if (!all) T = block_radix_select(C, rerank_k, key, r.rhist, s.misc, budget);
     uint32_t *sp = sel_pos + (uint64_t)q * sel_stride, *sk = sel_key + (uint64_t)q * sel_stride;
-    auto emit = [&](uint32_t i, uint32_t, uint32_t rank) {
+    auto emit = [&](uint32_t i, uint32_t, uint32_t, uint32_t rank) {
         if (rank < sel_stride) {
             uint32_t sl = scan_slot_of(s.lscan, nl, i);
             sp[rank] = s.lbeg[sl] + (i - s.lscan[sl]);
@@ -168,9 +169,9 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
     if (all) {
         // every candidate is selected: keys compare below the sentinel except NaN estimates, which
         // the sentinel-equal budget admits as well
-        ordered_threshold_compact(C, 0xFFFFFFFFu, C, key, emit, s.wtmp);
+        ordered_threshold_compact_aux(C, 0xFFFFFFFFu, C, key2, emit, s.wtmp);
     } else {
-        ordered_threshold_compact(C, T, budget, key, emit, s.wtmp);
+        ordered_threshold_compact_aux(C, T, budget, key2, emit, s.wtmp);
     }
     if (tid == 0) sel_count[q] = min(min(C, rerank_k), sel_stride);
 }

@@ -36,14 +36,21 @@ class SearchStats:
 class DeviceIndex:
     """Owns one `cuddle_index` handle (device-resident index + workspace)."""
 
-    def __init__(self, flat: FlatIndex, device_id: int = 0):
-        self.flat = flat.normalised()
+    def __init__(self, flat: Optional[FlatIndex], device_id: int = 0, desc: Optional[_ffi.IndexDesc] = None,
+                 keepalive=None):
+        """From a host FlatIndex, or from a ready `desc` (e.g. with CUDDLE_DESC_DEVICE_ARRAYS: see
+        vectordb_amd/synthetic.py) whose arrays `keepalive` keeps referenced."""
         self._lib = _ffi.lib()
         self._handle = C.c_void_p(None)
-        desc = self.flat.desc()
+        self._keepalive = keepalive
+        if desc is None:
+            self.flat = flat.normalised()
+            desc = self.flat.desc()
+        else:
+            self.flat = flat
         _ffi.check(self._lib.cuddle_index_create(C.byref(desc), int(device_id), C.byref(self._handle)))
         self.device_id = int(device_id)
-        self.dim = self.flat.dim
+        self.dim = int(desc.dim)
         self.levels = int(self._lib.cuddle_index_levels(self._handle))
         self.max_leaf_size = int(self._lib.cuddle_index_max_leaf_size(self._handle))
         self.max_children = int(self._lib.cuddle_index_max_children(self._handle))

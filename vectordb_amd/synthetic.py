@@ -1,0 +1,149 @@
+"""Index-by-construction for the large synthetic shards (100M - 1B vector configs): a hierarchical
+Gaussian whose tree is known from the generator, produced directly on the GPU in leaf-contiguous
+order and handed to the library as device arrays (CUDDLE_DESC_DEVICE_ARRAYS | ADOPT_VECTORS), so a
+64 GB shard is never copied through the host. k-means is not run: the reference's build takes
+837 s for 1M x 1024-d (/root/reference/benches/saved/jan_29_1M_vectors/shell_output.txt:27) and is
+not part of the query path; any tree with centroids is a valid input of `search`.
+
+Tree: `levels` levels of `fanout`-way nodes (level 0 = roots), the last level's nodes are leaves of
+`leaf_size` vectors each. Node ids are breadth-first. Leaf centroid = mean of its vectors, inner
+centroid = mean of its children's centroids.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .flat_index import FlatIndex
+
+
+@dataclass
+class DeviceTreeIndex:
+    dim: int
+    metric: int
+    threshold: float
+    child_offsets: np.ndarray   # host u32
+    children: np.ndarray        # host u32
+    roots: np.ndarray           # host u32
+    vec_offsets: np.ndarray     # host u64
+    centroids: torch.Tensor     # device f32 [n_nodes, dim]
+    ids: torch.Tensor           # device i64 [N]
+    vectors: torch.Tensor       # device f32 [N, dim]
+    codes: torch.Tensor         # device i64 [N, W]
+
+    @property
+    def n_vectors(self) -> int:
+        return int(self.ids.shape[0])
+
+    def desc(self) -> _ffi.IndexDesc:
+        d = _ffi.IndexDesc()
+        d.abi_version = _ffi.ABI_VERSION
+        d.dim, d.metric, d.code_kind = self.dim, self.metric, _ffi.CODE_BINARY
+        d.n_nodes, d.n_roots, d.n_vectors = int(self.centroids.shape[0]), int(self.roots.shape[0]), self.n_vectors
+        d.child_offsets = C.c_void_p(self.child_offsets.ctypes.data)
+        d.children = C.c_void_p(self.children.ctypes.data)
+        d.roots = C.c_void_p(self.roots.ctypes.data)
+        d.vec_offsets = C.c_void_p(self.vec_offsets.ctypes.data)
+        d.centroids = C.c_void_p(self.centroids.data_ptr())
+        d.ids = C.c_void_p(self.ids.data_ptr())
+        d.vectors = C.c_void_p(self.vectors.data_ptr())
+        d.codes = C.c_void_p(self.codes.data_ptr())
+        d.threshold = self.threshold
+        d.flags = _ffi.DESC_DEVICE_ARRAYS | _ffi.DESC_ADOPT_VECTORS
+        return d
+
+    def create(self, device_id: int):
+        from .index import DeviceIndex
+
+        torch.cuda.synchronize()
+        return DeviceIndex(None, device_id, desc=self.desc(), keepalive=self)
+
+    def to_flat(self) -> FlatIndex:
+        """Host copy (small cases: lets the oracle check the same index)."""
+        return FlatIndex(dim=self.dim, metric=self.metric, code_kind=_ffi.CODE_BINARY,
+                         centroids=self.centroids.cpu().numpy(), child_offsets=self.child_offsets, children=self.children,
+                         roots=self.roots, vec_offsets=self.vec_offsets, ids=self.ids.cpu().numpy().astype(np.uint64),
+                         vectors=self.vectors.cpu().numpy(), threshold=self.threshold,
+                         codes=self.codes.cpu().numpy().view(np.uint64)).normalised()
+
+
+def _pack_codes(x: torch.Tensor, threshold: float) -> torch.Tensor:
+    n, d = x.shape
+    words = (d + 63) // 64
+    b = torch.zeros((n, words * 64), dtype=torch.int64, device=x.device)
+    b[:, :d] = (x > threshold).to(torch.int64)
+    sh = torch.arange(32, device=x.device, dtype=torch.int64)
+    halves = (b.view(n, words, 2, 32) << sh).sum(-1)
+    return halves[..., 0] | (halves[..., 1] << 32)
+
+
+def build_tree_index_on_device(dim: int, fanout: int, levels: int, leaf_size: int, device, seed: int = 0,
+                               sigmas=(0.35, 0.22, 0.12), metric: int = _ffi.METRIC_L2, style: str = "sift",
+                               n_queries: int = 0, chunk_leaves: int = 8192):
+    """Returns (DeviceTreeIndex, queries [n_queries, dim]). N = fanout**levels * leaf_size vectors.
+    sigmas: spread of each level's centres around its parent, last entry = spread of the points
+    around their leaf centre. style "sift": values mapped to non-negative integers in the u8 range."""
+    assert levels >= 1 and len(sigmas) >= 2
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    widths = [fanout ** (l + 1) for l in range(levels)]
+    offs = np.concatenate([[0], np.cumsum(widths)]).astype(np.int64)
+    n_nodes, n_leaves = int(offs[-1]), widths[-1]
+    n_vec = n_leaves * leaf_size
+    # generating centres, level by level
+    centres = [torch.rand((widths[0], dim), generator=g, device=device) * 2 - 1]
+    for l in range(1, levels):
+        s = sigmas[min(l - 1, len(sigmas) - 2)]
+        parent = centres[-1].repeat_interleave(fanout, dim=0)
+        centres.append(parent + s * torch.randn((widths[l], dim), generator=g, device=device))
+    sig_pts = sigmas[-1]
+
+    def finish(x):
+        if style == "sift":
+            return torch.clamp(torch.round((x + 1.8) * 50.0), 0, 255)
+        return x
+
+    vectors = torch.empty((n_vec, dim), dtype=torch.float32, device=device)
+    leaf_cent = torch.empty((n_leaves, dim), dtype=torch.float32, device=device)
+    total = torch.zeros((), dtype=torch.float64, device=device)
+    for a in range(0, n_leaves, chunk_leaves):
+        b = min(a + chunk_leaves, n_leaves)
+        x = centres[-1][a:b, None, :] + sig_pts * torch.randn((b - a, leaf_size, dim), generator=g, device=device)
+        x = finish(x)
+        leaf_cent[a:b] = x.mean(dim=1)
+        total += x.double().sum()
+        vectors[a * leaf_size:b * leaf_size] = x.reshape(-1, dim)
+    threshold = float((total / (n_vec * dim)).item())
+    codes = torch.empty((n_vec, (dim + 63) // 64), dtype=torch.int64, device=device)
+    step = 1 << 20
+    for a in range(0, n_vec, step):
+        codes[a:a + step] = _pack_codes(vectors[a:a + step], threshold)
+    # centroids bottom-up
+    cents = [None] * levels
+    cents[-1] = leaf_cent
+    for l in range(levels - 2, -1, -1):
+        cents[l] = cents[l + 1].view(widths[l], fanout, dim).mean(dim=1)
+    centroids = torch.cat(cents, dim=0).contiguous()
+    # tree arrays (host)
+    child_offsets = np.zeros(n_nodes + 1, dtype=np.uint32)
+    counts = np.zeros(n_nodes, dtype=np.int64)
+    counts[:offs[levels - 1]] = fanout
+    child_offsets[1:] = np.cumsum(counts)
+    children = np.arange(offs[1], n_nodes, dtype=np.uint32) if levels > 1 else np.zeros(0, dtype=np.uint32)
+    vec_counts = np.zeros(n_nodes, dtype=np.int64)
+    vec_counts[offs[levels - 1]:] = leaf_size
+    vec_offsets = np.zeros(n_nodes + 1, dtype=np.uint64)
+    vec_offsets[1:] = np.cumsum(vec_counts)
+    roots = np.arange(widths[0], dtype=np.uint32)
+    ids = torch.arange(n_vec, dtype=torch.int64, device=device)
+    queries = torch.empty((0, dim), device=device)
+    if n_queries:
+        leaf = torch.randint(0, n_leaves, (n_queries,), generator=g, device=device)
+        queries = finish(centres[-1][leaf] + sig_pts * torch.randn((n_queries, dim), generator=g, device=device))
+    idx = DeviceTreeIndex(dim=dim, metric=metric, threshold=threshold, child_offsets=child_offsets, children=children,
+                          roots=roots, vec_offsets=vec_offsets, centroids=centroids, ids=ids, vectors=vectors, codes=codes)
+    return idx, queries.contiguous()
