@@ -65,6 +65,9 @@ typedef enum cuddle_code_kind { CUDDLE_CODE_BINARY = 0, CUDDLE_CODE_RABITQ = 1 }
 /* Route dense levels with the MFMA contraction + exact refinement (default) or force the
  * all-exact VALU routing kernel (bit-identical results; used for A/B measurements). */
 #define CUDDLE_SEARCH_ROUTE_EXACT_ONLY 0x4u
+/* Evaluate every level whose frontiers differ per query grouped by parent node, even where the
+ * library would judge the frontiers too narrow for that to pay (bit-identical results; tests). */
+#define CUDDLE_SEARCH_ROUTE_GROUPED 0x8u
 
 /* Flat description of one index (or one leaf shard of it). Mirrors ClusteredIndex's public
  * fields nodes/root_ids/quantizer/binary_vectors/full_vectors (hierarchical.rs:51-70) and

@@ -103,6 +103,34 @@ def test_mfma_routing_is_exact(gpu, metric):
     _compare_full(fi, dev, q[:40], 10, probes, 5)
 
 
+@pytest.mark.parametrize("metric,d", [("l2", 64), ("cosine", 48), ("dot", 37), ("l2", 200), ("cosine", 272), ("dot", 300)])
+def test_grouped_routing_is_exact(gpu, metric, d):
+    """Three levels: the roots are cut to `probes`, so the second level's frontier differs per query
+    and (being wider than 100 nodes) is evaluated grouped by parent; leaf lists must equal the
+    all-exact kernels' and the oracle's, for search() and for the always-sorting stats variant.
+    probes = 40 also exercises a mixed batch: queries whose frontier happens to stay small."""
+    orc = _oracle()
+    x = clustered(40000, d, 200, 13, sigma=0.3)
+    from vectordb_amd.builder import build_index
+    fi = build_index(x, 30, 20, metric, 6, seed=5)
+    assert fi.n_levels() >= 3
+    dev = DeviceIndex(fi, gpu)
+    oi = orc.OracleIndex(fi)
+    q = queries_like(x, 150, 9, noise=0.1)
+    for probes in (8, 40):
+        for flags in (0, _ffi.SEARCH_STATS_VARIANT):
+            lv_g, lc_g = dev.route_batch(q, probes, flags | _ffi.SEARCH_ROUTE_GROUPED)
+            lv_e, lc_e = dev.route_batch(q, probes, flags | _ffi.SEARCH_ROUTE_EXACT_ONLY)
+            assert np.array_equal(lc_g, lc_e)
+            for i in range(q.shape[0]):
+                assert np.array_equal(lv_g[i, :lc_g[i]], lv_e[i, :lc_e[i]]), (probes, flags, i)
+            for i in range(0, q.shape[0], 11):
+                t = oi.search(q[i], 10, probes, 5, flags, trace=True)
+                assert np.array_equal(lv_g[i, :lc_g[i]], t["leaves"]), (probes, flags, i)
+    _compare_full(fi, dev, q[:30], 10, 8, 5, _ffi.SEARCH_ROUTE_GROUPED)
+    _compare_full(fi, dev, q[:30], 10, 8, 5, _ffi.SEARCH_ROUTE_GROUPED | _ffi.SEARCH_STATS_VARIANT)
+
+
 @pytest.mark.parametrize("metric,d", [("l2", 64), ("cosine", 96), ("dot", 40)])
 def test_rabitq_search_matches_oracle(gpu, metric, d):
     """RaBitQ phase 1: rotation, estimates, f32 selection, rerank, top-k — all bit-exact."""

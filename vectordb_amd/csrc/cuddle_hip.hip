@@ -112,6 +112,9 @@ struct Plan {
     float *fdist = nullptr;
     uint32_t *leaves = nullptr, *lcount = nullptr;
     uint16_t *gdist = nullptr;
+    // (query, parent) pairs of the grouped routing level
+    uint32_t *pair_info = nullptr, *pair_parent = nullptr, *pair_sorted = nullptr, *small_flag = nullptr;
+    uint32_t *grp_cnt = nullptr, *grp_poff = nullptr, *grp_ioff = nullptr, *grp_fill = nullptr, *grp_item = nullptr;
     uint32_t *sel_pos = nullptr, *sel_key = nullptr, *sel_count = nullptr, *cand_count = nullptr;
     float *sel_dist = nullptr;
     // MFMA routing
@@ -143,6 +146,7 @@ struct cuddle_index {
     std::vector<uint32_t> level_width;
     std::vector<LevelGemm> lvl;
     std::vector<uint32_t> level_leaves; // leaf nodes per level
+    uint32_t max_parent_width = 1;      // widest level that has a level below it
     DevBuf ws;       // per-chunk work space (Plan)
     DevBuf io;       // staging for the host entry points
     DevStats *d_stats = nullptr;
@@ -385,10 +389,20 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     // operands of the MFMA routing contraction, for every level wide enough to use it
     ix->lvl.assign(n_levels, LevelGemm());
     ix->level_leaves.assign(n_levels, 0);
-    for (uint32_t l = 0; l < n_levels; ++l) {
-        for (uint32_t v2 : level_nodes[l])
-            if (d->child_offsets[v2 + 1] == d->child_offsets[v2]) ix->level_leaves[l]++;
-        ST_TRY(upload(ix, level_nodes[l].data(), level_nodes[l].size(), &ix->lvl[l].nodes));
+    {
+        std::vector<uint32_t> level_pos(n, 0);
+        for (uint32_t l = 0; l < n_levels; ++l) {
+            for (size_t i = 0; i < level_nodes[l].size(); ++i) {
+                const uint32_t v2 = level_nodes[l][i];
+                level_pos[v2] = (uint32_t)i;
+                if (d->child_offsets[v2 + 1] == d->child_offsets[v2]) ix->level_leaves[l]++;
+            }
+            if (l + 1 < n_levels) ix->max_parent_width = std::max(ix->max_parent_width, (uint32_t)level_nodes[l].size());
+            ST_TRY(upload(ix, level_nodes[l].data(), level_nodes[l].size(), &ix->lvl[l].nodes));
+        }
+        uint32_t *lp;
+        ST_TRY(upload(ix, level_pos.data(), (size_t)n, &lp));
+        v.level_pos = lp;
     }
     if (D % 4 == 0) {
         for (uint32_t l = 0; l < n_levels; ++l) {
@@ -486,6 +500,9 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     (void)hipFuncSetAttribute((const void *)scan_kernel_for(v.dim, v.words), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_all_hamming_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_dist_grouped_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_select_rabitq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_all_rabitq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -585,6 +602,10 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     size_t o_qcent = carve(qc * v.dim * 4), o_qsq = carve(qc * 4);
     size_t o_rcp = carve(qc * pl.kc_cap * 4), o_rcd = carve(qc * pl.kc_cap * 4), o_rcm = carve(qc * 4), o_rfl = carve(qc * 4);
     size_t o_ord = carve(qc * 4);
+    const size_t gw = (size_t)ix->max_parent_width + 1;
+    size_t o_pi = carve(qc * pl.probes * 4), o_pp = carve(qc * pl.probes * 4), o_ps = carve(qc * pl.probes * 4);
+    size_t o_sf = carve(qc * 4), o_gc = carve(gw * 4), o_gp = carve(gw * 4), o_gi = carve(gw * 4), o_gf = carve(gw * 4);
+    size_t o_git = carve((qc * pl.probes / kGroupPairs + gw + 1) * 4);
     pl.bytes = off;
     ST_TRY(ix->ws.ensure(pl.bytes));
     char *b = static_cast<char *>(ix->ws.p);
@@ -600,6 +621,11 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     pl.rc_pos = (uint32_t *)(b + o_rcp); pl.rc_dist = (float *)(b + o_rcd); pl.rc_max = (float *)(b + o_rcm);
     pl.rflag = (uint32_t *)(b + o_rfl);
     pl.order = (uint32_t *)(b + o_ord);
+    pl.pair_info = (uint32_t *)(b + o_pi); pl.pair_parent = (uint32_t *)(b + o_pp); pl.pair_sorted = (uint32_t *)(b + o_ps);
+    pl.small_flag = (uint32_t *)(b + o_sf);
+    pl.grp_cnt = (uint32_t *)(b + o_gc); pl.grp_poff = (uint32_t *)(b + o_gp); pl.grp_ioff = (uint32_t *)(b + o_gi);
+    pl.grp_fill = (uint32_t *)(b + o_gf);
+    pl.grp_item = (uint32_t *)(b + o_git);
     return CUDDLE_OK;
 }
 
@@ -663,6 +689,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                        pl.frontier[0], pl.fstride, pl.fcount[0], pl.lcount, nq, shared ? 0u : 1u);
     int cur = 0;
     uint64_t fb = v.n_roots;
+    bool grouped = false; // this level's distances come from the (query, parent) pairs of the level above
     for (uint32_t l = 0; l < ix->n_levels; ++l) {
         fb = std::min<uint64_t>(fb, ix->level_width[l]);
         const uint32_t bound = (uint32_t)std::max<uint64_t>(fb, 1);
@@ -672,13 +699,45 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         const uint32_t *sfr = shared ? g.nodes : nullptr;
         const uint32_t sn = shared ? ix->level_width[l] : 0;
         const bool next_shared = shared && keep_all;
+        const uint64_t fb_next = std::min<uint64_t>(fb, pl.probes) * std::max<uint32_t>(ix->max_children, 1);
         if (shared && keep_all && ix->level_leaves[l] == 0) {
             // every node of the level is kept and none is a leaf: nothing to compute or record
-            fb = std::min<uint64_t>(fb, pl.probes) * std::max<uint32_t>(ix->max_children, 1);
+            fb = fb_next;
             continue;
         }
-        const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound;
         const uint32_t *only = nullptr;
+        if (grouped) {
+            // pairs recorded by the level above -> parent order -> one block per (parent, 8 queries)
+            const uint32_t wprev = ix->level_width[l - 1], total = nq * pl.probes;
+            hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, pl.grp_cnt, wprev, pl.grp_poff, pl.grp_ioff, pl.grp_fill,
+                               pl.grp_item);
+            hipLaunchKernelGGL(pair_fill_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pl.pair_info, pl.pair_parent, total,
+                               pl.grp_poff, pl.grp_fill, pl.pair_sorted);
+            const uint32_t items = (total + kGroupPairs - 1) / kGroupPairs + std::min(wprev, total);
+            const size_t glds = (size_t)kGroupNQ * ((v.dim + 3) & ~3u) * sizeof(float);
+            auto gk = v.dim <= 128 ? route_dist_grouped_kernel<8> : v.dim <= 256 ? route_dist_grouped_kernel<16> : route_dist_grouped_kernel<0>;
+            hipLaunchKernelGGL(gk, dim3(items), dim3(256), glds, s, v, dq, ix->lvl[l - 1].nodes, wprev, pl.grp_poff, pl.grp_ioff,
+                               pl.grp_item, pl.pair_sorted, pl.fdist, pl.fstride);
+            only = pl.small_flag; // queries with small frontiers: the exact kernel below, in their own arithmetic
+        }
+        // Will the next level evaluate per-query frontiers wider than probes? Then this level's
+        // expansion also records its (query, chosen node) pairs, grouped by node for that level.
+        PairOut po;
+        bool group_next = false;
+        if (l + 1 < ix->n_levels && !next_shared && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && pl.fstride <= (1u << kPairOffBits)) {
+            // grouping has a fixed cost (pair sort, one block per 64 pairs): worth it when a query's
+            // next frontier is expected to be wide, i.e. chosen nodes x mean fan-out of this level
+            const uint64_t bound_next = std::min<uint64_t>(fb_next, ix->level_width[l + 1]);
+            const uint64_t expect_next = std::min<uint64_t>(fb, pl.probes) * ix->level_width[l + 1] / std::max<uint32_t>(ix->level_width[l], 1);
+            if ((stats || bound_next > std::max<uint32_t>(pl.probes, 100)) && (expect_next >= 256 || (flags & CUDDLE_SEARCH_ROUTE_GROUPED))) {
+                group_next = true;
+                po.info = pl.pair_info; po.parent = pl.pair_parent; po.cnt = pl.grp_cnt; po.small = pl.small_flag;
+                po.pstride = pl.probes;
+                po.min_n = stats ? 0u : std::max<uint32_t>(pl.probes, 100);
+                HIP_TRY(hipMemsetAsync(pl.grp_cnt, 0, ((size_t)ix->level_width[l] + 1) * 4, s));
+            }
+        }
+        const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound;
         if (use_gemm) {
             const uint32_t n = g.n, kc = std::min(n, pl.kc_cap);
             hipLaunchKernelGGL(center_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, pl.qcent, pl.qsq);
@@ -692,8 +751,14 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             else
                 hipLaunchKernelGGL(route_gemm_kernel<2>, dim3(8 * ((gx2 + 7) / 8) * gy), dim3(256), route_gemm_lds_bytes(2), s,
                                    pl.qcent, pl.qsq, g.table, g.sqn, nq, n, v.dim, v.metric, pl.fdist, pl.fstride, gx2, gy);
-            if (n <= (uint32_t)kPrefKpt * kPrefThreads)
-                hipLaunchKernelGGL(route_prefilter_reg_kernel, dim3(nq), dim3(kPrefThreads), 0, s, pl.fdist, pl.fstride, n, kc,
+            if (n <= (uint32_t)kPrefKpt * 128)
+                hipLaunchKernelGGL(route_prefilter_reg_kernel<128>, dim3(nq), dim3(128), 0, s, pl.fdist, pl.fstride, n, kc,
+                                   pl.rc_pos, pl.kc_cap, pl.rc_max);
+            else if (n <= (uint32_t)kPrefKpt * 256)
+                hipLaunchKernelGGL(route_prefilter_reg_kernel<256>, dim3(nq), dim3(256), 0, s, pl.fdist, pl.fstride, n, kc,
+                                   pl.rc_pos, pl.kc_cap, pl.rc_max);
+            else if (n <= (uint32_t)kPrefKpt * 512)
+                hipLaunchKernelGGL(route_prefilter_reg_kernel<512>, dim3(nq), dim3(512), 0, s, pl.fdist, pl.fstride, n, kc,
                                    pl.rc_pos, pl.kc_cap, pl.rc_max);
             else
                 hipLaunchKernelGGL(route_prefilter_kernel, dim3(nq), dim3(256), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,
@@ -703,19 +768,32 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(kc), pl.probes), s,
                                v, g.nodes, n, pl.rc_pos, pl.rc_dist, pl.kc_cap, kc, pl.rc_max, pl.qsq, g.max_sqn, pl.probes,
                                pl.frontier[cur ^ 1], pl.fstride, pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,
-                               pl.rflag, &ix->d_stats->fallbacks);
+                               pl.rflag, &ix->d_stats->fallbacks, po);
             only = pl.rflag; // queries whose selection could not be proven exact fall through to the exact kernels
         }
-        if (!keep_all) // after the MFMA path only the (rare) flagged queries do work here: few blocks per query
-            hipLaunchKernelGGL(route_dist_kernel, dim3(use_gemm ? 4 : std::min<uint32_t>((bound + 63) / 64, 64), nq), dim3(256), v.dim * sizeof(float), s, v, dq,
+        if (!keep_all) // after the MFMA or grouped path only the (rare) flagged queries do work here: few blocks per query
+            hipLaunchKernelGGL(route_dist_kernel, dim3((use_gemm || grouped) ? 4 : std::min<uint32_t>((bound + 63) / 64, 64), nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                pl.frontier[cur], pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, only);
-        hipLaunchKernelGGL(route_select_kernel, dim3(nq), dim3(256), route_select_lds_bytes(scap), s, v, pl.frontier[cur],
-                           pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, scap,
-                           next_shared ? nullptr : pl.frontier[cur ^ 1], pl.fcount[cur ^ 1], pl.leaves, pl.lstride,
-                           pl.lcount, only);
+        const uint32_t *sel_only = grouped ? nullptr : only; // after the grouped path every query still selects here
+        if (!keep_all && bound <= (uint32_t)kSelKpt * 256)
+            hipLaunchKernelGGL(route_select_reg_kernel<256>, dim3(nq), dim3(256), route_select_lds_bytes(scap), s, v, pl.frontier[cur],
+                               pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, scap,
+                               next_shared ? nullptr : pl.frontier[cur ^ 1], pl.fcount[cur ^ 1], pl.leaves, pl.lstride,
+                               pl.lcount, sel_only, po);
+        else if (!keep_all && bound <= (uint32_t)kSelKpt * 512)
+            hipLaunchKernelGGL(route_select_reg_kernel<512>, dim3(nq), dim3(512), route_select_lds_bytes(scap), s, v, pl.frontier[cur],
+                               pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, scap,
+                               next_shared ? nullptr : pl.frontier[cur ^ 1], pl.fcount[cur ^ 1], pl.leaves, pl.lstride,
+                               pl.lcount, sel_only, po);
+        else
+            hipLaunchKernelGGL(route_select_kernel, dim3(nq), dim3(256), route_select_lds_bytes(scap), s, v, pl.frontier[cur],
+                               pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, scap,
+                               next_shared ? nullptr : pl.frontier[cur ^ 1], pl.fcount[cur ^ 1], pl.leaves, pl.lstride,
+                               pl.lcount, sel_only, po);
         cur ^= 1;
         shared = next_shared;
-        fb = std::min<uint64_t>(fb, pl.probes) * std::max<uint32_t>(ix->max_children, 1);
+        grouped = group_next;
+        fb = fb_next;
     }
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;

@@ -30,6 +30,7 @@ struct IndexDev {
     const uint32_t *child_off;    // [n_nodes+1]
     const uint32_t *children;
     const uint32_t *roots;
+    const uint32_t *level_pos;    // [n_nodes]   position of the node in its level's breadth-first node list
     const uint32_t *vec_off;      // [n_nodes+1] leaf-contiguous positions
     const uint32_t *code_off;     // [n_nodes]   start of the leaf's planar code block, 16-byte units
     const uint64_t *ids;          // [n_vectors]
@@ -425,6 +426,73 @@ __device__ __forceinline__ float distance_group4(const float *a, const float *b,
     float na = sqrtf(neon16_group4<false>(a, a, n, sub, vec));
     float nb = sqrtf(neon16_group4<false>(b, b, n, sub, vec));
     return 1.0f - (dot / (na * nb));
+}
+
+// neon16_group4 for NQ query vectors (LDS, qstride floats apart) against one stored vector b: the
+// stored vector is read once, each query keeps its own accumulators; every result is the one
+// neon16_group4 gives for that pair.
+template <bool L2, int NQ>
+__device__ __forceinline__ void neon16_group4_multi(const float *qs, uint32_t qstride, const float *b, uint32_t n,
+                                                    uint32_t sub, bool vec, float *out) {
+    float4 acc[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t nblk = n >> 4;
+    const float *pa = qs + 4 * sub, *pb = b + 4 * sub;
+#pragma unroll 2
+    for (uint32_t t = 0; t < nblk; ++t) {
+        const float4 y = ld4(pb + 16 * t, vec);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const float4 x = ld4(pa + (uint32_t)j * qstride + 16 * t, vec);
+            if (L2) {
+                const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+                acc[j].x = __builtin_fmaf(d0, d0, acc[j].x);
+                acc[j].y = __builtin_fmaf(d1, d1, acc[j].y);
+                acc[j].z = __builtin_fmaf(d2, d2, acc[j].z);
+                acc[j].w = __builtin_fmaf(d3, d3, acc[j].w);
+            } else {
+                acc[j].x = __builtin_fmaf(x.x, y.x, acc[j].x);
+                acc[j].y = __builtin_fmaf(x.y, y.y, acc[j].y);
+                acc[j].z = __builtin_fmaf(x.z, y.z, acc[j].z);
+                acc[j].w = __builtin_fmaf(x.w, y.w, acc[j].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        float4 a = acc[j];
+        a.x += __shfl_xor(a.x, 1, 64); a.y += __shfl_xor(a.y, 1, 64);
+        a.z += __shfl_xor(a.z, 1, 64); a.w += __shfl_xor(a.w, 1, 64);
+        a.x += __shfl_xor(a.x, 2, 64); a.y += __shfl_xor(a.y, 2, 64);
+        a.z += __shfl_xor(a.z, 2, 64); a.w += __shfl_xor(a.w, 2, 64);
+        const float r = (a.x + a.y) + (a.z + a.w);
+        out[j] = neon_tail<L2>(r, qs + (uint32_t)j * qstride, b, nblk << 4, n);
+    }
+}
+
+// distance() of NQ queries (LDS) to one stored vector b by a 4-lane group; out[j] equals
+// distance_group4(query j, b).
+template <int NQ>
+__device__ __forceinline__ void distance_group4_multi(const float *qs, uint32_t qstride, const float *b, uint32_t n,
+                                                      uint32_t metric, uint32_t sub, bool vec, float *out) {
+    if (metric == kMetricL2) {
+        neon16_group4_multi<true, NQ>(qs, qstride, b, n, sub, vec, out);
+        return;
+    }
+    neon16_group4_multi<false, NQ>(qs, qstride, b, n, sub, vec, out);
+    if (metric == kMetricDot) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) out[j] = -out[j];
+        return;
+    }
+    const float nb = sqrtf(neon16_group4<false>(b, b, n, sub, vec));
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const float *a = qs + (uint32_t)j * qstride;
+        const float na = sqrtf(neon16_group4<false>(a, a, n, sub, vec));
+        out[j] = 1.0f - (out[j] / (na * nb));
+    }
 }
 
 __device__ __forceinline__ float distance_serial(const float *a, const float *b, uint32_t n, uint32_t metric) {

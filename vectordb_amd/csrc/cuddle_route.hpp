@@ -66,6 +66,26 @@ __device__ __forceinline__ uint32_t block_radix_select(uint32_t n, uint32_t want
     return prefix;
 }
 
+// Optional output of route_expand for the next level's grouped distance kernel: one (query, chosen
+// internal node) pair per selection slot, and the number of pairs per parent node.
+//   info[q * pstride + i]   = (q << 20) | position of the node's first child in the next frontier,
+//                             or 0xFFFFFFFF (slot unused, leaf, or query not grouped)
+//   parent[q * pstride + i] = level position of the node
+//   cnt[level position]    += 1 per pair
+//   small[q]                = 1 when the query's next frontier has at most min_n nodes (its distances
+//                             use the small-frontier arithmetic and are left to route_dist_kernel)
+struct PairOut {
+    uint32_t *info = nullptr;
+    uint32_t *parent = nullptr;
+    uint32_t *cnt = nullptr;
+    uint32_t *small = nullptr;
+    uint32_t pstride = 0;
+    uint32_t min_n = 0;
+};
+constexpr uint32_t kPairOffBits = 20; // next-frontier positions below 2^20, queries per chunk below 2^12
+constexpr int kGroupNQ = 8;           // queries per tile of route_dist_grouped_kernel
+constexpr int kGroupPairs = 64;       // pairs per block of route_dist_grouped_kernel (8 tiles)
+
 // Split the chosen nodes into leaves and internal nodes (hierarchical.rs:411-413), append the
 // leaves to the query's leaf list (:416) and write the children of the internal nodes, in order,
 // as the next frontier (:419-422; skipped when nf is null: the next level's frontier is then the
@@ -74,7 +94,7 @@ __device__ __forceinline__ uint32_t block_radix_select(uint32_t n, uint32_t want
 __device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t *fr, const uint64_t *skeys,
                                              uint32_t nsel, uint32_t *cnt_leaf, uint32_t *cnt_child, uint32_t *nf,
                                              uint32_t fstride, uint32_t *next_fcount_q, uint32_t *lv, uint32_t lstride,
-                                             uint32_t *lcount_q) {
+                                             uint32_t *lcount_q, const PairOut &po = PairOut(), uint32_t q = 0) {
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < nsel; i += blockDim.x) {
         uint32_t node = fr[(uint32_t)skeys[i]];
@@ -88,6 +108,21 @@ __device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t 
     wave0_exclusive_scan_lds(cnt_child, nsel);
     __syncthreads();
     const uint32_t lbase = *lcount_q;
+    if (po.info) {
+        const uint32_t nchild = cnt_child[nsel];
+        const bool grouped = nf && nchild > po.min_n && nchild <= fstride;
+        for (uint32_t i = tid; i < po.pstride; i += blockDim.x) {
+            uint32_t info = 0xFFFFFFFFu, par = 0;
+            if (grouped && i < nsel && cnt_child[i + 1] > cnt_child[i]) {
+                par = ix.level_pos[fr[(uint32_t)skeys[i]]];
+                info = (q << kPairOffBits) | cnt_child[i];
+                atomicAdd(&po.cnt[par], 1u);
+            }
+            po.info[(uint64_t)q * po.pstride + i] = info;
+            po.parent[(uint64_t)q * po.pstride + i] = par;
+        }
+        if (tid == 0) po.small[q] = grouped ? 0u : 1u;
+    }
     // one wave per chosen node: leaves are appended, children copied with coalesced stores
     const uint32_t nw = blockDim.x >> 6, w = tid >> 6, lane = tid & 63;
     for (uint32_t i = w; i < nsel; i += nw) {
@@ -190,7 +225,7 @@ __global__ void __launch_bounds__(256)
 route_select_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, const uint32_t *fcount,
                     const uint32_t *shared_fr, uint32_t shared_n, const float *fdist, uint32_t probes,
                     uint32_t stats_variant, uint32_t scap, uint32_t *next_frontier, uint32_t *next_fcount,
-                    uint32_t *leaves, uint32_t lstride, uint32_t *lcount, const uint32_t *only_flag) {
+                    uint32_t *leaves, uint32_t lstride, uint32_t *lcount, const uint32_t *only_flag, PairOut po) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);                 // [scap]
     uint32_t *hist = reinterpret_cast<uint32_t *>(skeys + scap);         // [256]
@@ -204,6 +239,10 @@ route_select_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, con
     const uint32_t tid = threadIdx.x;
     if (n == 0) {
         if (tid == 0 && next_frontier) next_fcount[q] = 0;
+        if (po.info) {
+            for (uint32_t i = tid; i < po.pstride; i += blockDim.x) po.info[(uint64_t)q * po.pstride + i] = 0xFFFFFFFFu;
+            if (tid == 0) po.small[q] = 1;
+        }
         return;
     }
     const uint32_t *fr = shared_fr ? shared_fr : frontier + (uint64_t)q * fstride;
@@ -236,7 +275,362 @@ route_select_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, con
     }
     route_expand(ix, fr, skeys, nsel, cnt_leaf, cnt_child,
                  next_frontier ? next_frontier + (uint64_t)q * fstride : nullptr, fstride, next_fcount + q,
-                 leaves + (uint64_t)q * lstride, lstride, lcount + q);
+                 leaves + (uint64_t)q * lstride, lstride, lcount + q, po, q);
+}
+
+constexpr int kSelKpt = 32; // register-resident selection: n <= 32 * THREADS
+
+// route_select_kernel for levels whose frontiers hold at most kSelKpt * THREADS nodes: the keys
+// are read once and kept in registers, radix passes whose digit is the same for every key are
+// skipped (no counting, no same-address atomics), and the winners are collected in any order
+// before the sort by (distance, frontier position) — unless the keys equal to the threshold
+// outnumber the places left for them, in which case the earliest positions must win and the
+// ordered compaction decides. Same arguments, same result; dynamic LDS = route_select_lds_bytes(scap).
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, const uint32_t *fcount,
+                        const uint32_t *shared_fr, uint32_t shared_n, const float *fdist, uint32_t probes,
+                        uint32_t stats_variant, uint32_t scap, uint32_t *next_frontier, uint32_t *next_fcount,
+                        uint32_t *leaves, uint32_t lstride, uint32_t *lcount, const uint32_t *only_flag, PairOut po) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);                 // [scap]
+    uint32_t *hist = reinterpret_cast<uint32_t *>(skeys + scap);         // [256]
+    uint32_t *wtmp = hist + 256;                                         // [2 * waves]
+    uint32_t *misc = wtmp + 32;                                          // [8]
+    uint32_t *cnt_leaf = misc + 8;                                       // [scap + 1]
+    uint32_t *cnt_child = cnt_leaf + scap + 1;                           // [scap + 1]
+    const uint32_t q = blockIdx.x;
+    if (only_flag && !only_flag[q]) return;
+    const uint32_t n = shared_fr ? shared_n : fcount[q];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (n == 0) {
+        if (tid == 0 && next_frontier) next_fcount[q] = 0;
+        if (po.info) {
+            for (uint32_t i = tid; i < po.pstride; i += blockDim.x) po.info[(uint64_t)q * po.pstride + i] = 0xFFFFFFFFu;
+            if (tid == 0) po.small[q] = 1;
+        }
+        return;
+    }
+    const uint32_t *fr = shared_fr ? shared_fr : frontier + (uint64_t)q * fstride;
+    const float *fd = fdist + (uint64_t)q * fstride;
+    uint32_t nsel;
+    const bool keep_all = !stats_variant && n <= probes;
+    if (keep_all) {
+        nsel = n;
+        for (uint32_t i = tid; i < n; i += blockDim.x) skeys[i] = i;
+        __syncthreads();
+    } else {
+        nsel = min(n, probes);
+        uint32_t npad;
+        if (n <= scap) {
+            npad = next_pow2(n);
+            for (uint32_t i = tid; i < npad; i += blockDim.x)
+                skeys[i] = i < n ? (((uint64_t)f32_key(fd[i]) << 32) | i) : ~0ull;
+            __syncthreads();
+        } else {
+            uint32_t keys[kSelKpt];
+            uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+            for (int t = 0; t < kSelKpt; ++t) {
+                const uint32_t i = t * THREADS + tid;
+                keys[t] = i < n ? f32_key(fd[i]) : 0xFFFFFFFFu;
+                if (i < n) {
+                    kmin = min(kmin, keys[t]);
+                    kmax = max(kmax, keys[t]);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
+                kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+            }
+            if (lane == 0) {
+                wtmp[w] = kmin;
+                wtmp[THREADS / 64 + w] = kmax;
+            }
+            if (tid < 2) misc[2 + tid] = 0; // winner counter, tie counter
+            __syncthreads();
+            for (uint32_t v = 0; v < THREADS / 64; ++v) {
+                kmin = min(kmin, wtmp[v]);
+                kmax = max(kmax, wtmp[THREADS / 64 + v]);
+            }
+            uint32_t prefix = 0, want = nsel;
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                if ((kmin >> shift) == (kmax >> shift)) { // every key has this digit (and all higher bits) in common
+                    prefix |= ((kmin >> shift) & 255u) << shift;
+                    continue;
+                }
+                for (uint32_t i = tid; i < 256; i += THREADS) hist[i] = 0;
+                __syncthreads();
+                const uint32_t himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+#pragma unroll
+                for (int t = 0; t < kSelKpt; ++t) {
+                    const uint32_t i = t * THREADS + tid;
+                    if (i < n && (keys[t] & himask) == prefix) atomicAdd(&hist[(keys[t] >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (tid < 64) {
+                    const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                    const uint32_t s4 = h0 + h1 + h2 + h3;
+                    const uint32_t incl = wave_inclusive_sum(s4);
+                    const uint64_t hit = __ballot(incl >= want);
+                    const uint32_t first = hit ? (uint32_t)__ffsll((unsigned long long)hit) - 1 : 63u;
+                    if (tid == first) {
+                        uint32_t cum = incl - s4, b = 4 * tid;
+                        if (cum + h0 < want) { cum += h0; ++b;
+                            if (cum + h1 < want) { cum += h1; ++b;
+                                if (cum + h2 < want) { cum += h2; ++b; } } }
+                        misc[0] = prefix | (b << shift);
+                        misc[1] = want - cum;
+                    }
+                }
+                __syncthreads();
+                prefix = misc[0];
+                want = misc[1];
+                __syncthreads();
+            }
+            const uint32_t T = prefix, budget = want;
+            uint32_t my_ties = 0;
+#pragma unroll
+            for (int t = 0; t < kSelKpt; ++t) my_ties += (t * THREADS + tid < n && keys[t] == T) ? 1u : 0u;
+            if (my_ties) atomicAdd(&misc[3], my_ties);
+            __syncthreads();
+            if (misc[3] == budget) { // every key equal to the threshold is selected: order is the sort's business
+#pragma unroll
+                for (int t = 0; t < kSelKpt; ++t) {
+                    const uint32_t i = t * THREADS + tid;
+                    if (i < n && keys[t] <= T) skeys[atomicAdd(&misc[2], 1u)] = ((uint64_t)keys[t] << 32) | i;
+                }
+            } else {
+                ordered_threshold_compact(
+                    n, T, budget, [&](uint32_t i) { return f32_key(fd[i]); },
+                    [&](uint32_t i, uint32_t kv, uint32_t rank) { skeys[rank] = ((uint64_t)kv << 32) | i; }, wtmp);
+            }
+            npad = next_pow2(nsel);
+            for (uint32_t i = nsel + tid; i < npad; i += blockDim.x) skeys[i] = ~0ull;
+            __syncthreads();
+        }
+        block_bitonic_sort_u64(skeys, npad);
+    }
+    route_expand(ix, fr, skeys, nsel, cnt_leaf, cnt_child,
+                 next_frontier ? next_frontier + (uint64_t)q * fstride : nullptr, fstride, next_fcount + q,
+                 leaves + (uint64_t)q * lstride, lstride, lcount + q, po, q);
+}
+
+// ---------------------------------------------------------------------------------------------
+// grouped exact distances for a level whose frontiers differ per query
+// ---------------------------------------------------------------------------------------------
+// The frontier of such a level is, per query, the children of the nodes chosen one level up. Many
+// queries choose the same parents, so the (query, parent) pairs are grouped by parent and one block
+// evaluates kGroupNQ queries of a group against the parent's children: every centroid row is read
+// once per block instead of once per query. The arithmetic per (query, child) is distance(), as
+// search() uses for frontiers of more than 100 nodes (hierarchical.rs:355-365); queries with
+// smaller frontiers are not grouped (PairOut::small).
+
+// Exclusive prefix sums over the per-parent pair counts: poff = pairs, ioff = work items (blocks of
+// up to kGroupPairs pairs of one parent); item_parent[item] = its parent; also clears the fill
+// counters. One block of 1024 threads; the per-parent arrays hold n + 1 entries.
+__global__ void __launch_bounds__(1024)
+pair_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *poff, uint32_t *ioff, uint32_t *fill, uint32_t *item_parent) {
+    __shared__ uint32_t sp[1024], si[1024];
+    const uint32_t tid = threadIdx.x, per = (n + 1023) / 1024;
+    const uint32_t b = min(tid * per, n), e = min(b + per, n);
+    uint32_t ap = 0, ai = 0;
+    for (uint32_t i = b; i < e; ++i) {
+        ap += cnt[i];
+        ai += (cnt[i] + kGroupPairs - 1) / kGroupPairs;
+    }
+    sp[tid] = ap;
+    si[tid] = ai;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint32_t vp = tid >= o ? sp[tid - o] : 0, vi = tid >= o ? si[tid - o] : 0;
+        __syncthreads();
+        sp[tid] += vp;
+        si[tid] += vi;
+        __syncthreads();
+    }
+    uint32_t rp = sp[tid] - ap, ri = si[tid] - ai;
+    for (uint32_t i = b; i < e; ++i) {
+        const uint32_t c = cnt[i], ni = (c + kGroupPairs - 1) / kGroupPairs;
+        poff[i] = rp;
+        ioff[i] = ri;
+        fill[i] = 0;
+        for (uint32_t t = 0; t < ni; ++t) item_parent[ri + t] = i;
+        rp += c;
+        ri += ni;
+    }
+    if (tid == 1023) {
+        poff[n] = sp[1023];
+        ioff[n] = si[1023];
+    }
+}
+
+// Scatter the pairs into parent order (order inside a group is immaterial).
+__global__ void pair_fill_kernel(const uint32_t *info, const uint32_t *parent, uint32_t total, const uint32_t *poff,
+                                 uint32_t *fill, uint32_t *sorted) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t v = info[i];
+    if (v == 0xFFFFFFFFu) return;
+    const uint32_t p = parent[i];
+    sorted[poff[p] + atomicAdd(&fill[p], 1u)] = v;
+}
+
+// One block per work item = (parent, up to kGroupPairs of its pairs); blocks past the last item
+// exit. block = 256: one 4-lane group per child (64 children per pass) keeps its slice of the
+// child's centroid in registers (RCH chunks of 16 dimensions, dim <= 16 * RCH; RCH = 0: any dim,
+// the slice is re-read in segments of 8 chunks for every tile) while the item's pairs go by in
+// tiles of kGroupNQ queries staged in LDS.
+// dynamic LDS = kGroupNQ * pad4(dim) floats.
+template <int RCH>
+__global__ void __launch_bounds__(256)
+route_dist_grouped_kernel(IndexDev ix, const float *queries, const uint32_t *level_nodes, uint32_t n_parents,
+                          const uint32_t *poff, const uint32_t *ioff, const uint32_t *item_parent,
+                          const uint32_t *sorted, float *fdist, uint32_t fstride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *qs = reinterpret_cast<float *>(smem);
+    __shared__ uint32_t pk[kGroupPairs];
+    const uint32_t item = blockIdx.x;
+    if (item >= ioff[n_parents]) return;
+    const uint32_t p = item_parent[item], D = ix.dim, Dp = (D + 3) & ~3u, tid = threadIdx.x;
+    const uint32_t pb = poff[p] + (item - ioff[p]) * kGroupPairs, np = min((uint32_t)kGroupPairs, poff[p + 1] - pb);
+    if (tid < kGroupPairs) pk[tid] = sorted[pb + min(tid, np - 1)]; // unused slots repeat the last pair
+    const uint32_t node = level_nodes[p];
+    const uint32_t cb = ix.child_off[node], cc = ix.child_off[node + 1] - cb;
+    const uint32_t sub = tid & 3, nblk = D >> 4;
+    const bool vec = (D & 3) == 0;
+    for (uint32_t c0 = 0; c0 < cc; c0 += 64) { // block-uniform trip counts throughout
+        const uint32_t c = c0 + (tid >> 2);
+        const bool act = c < cc;
+        const float *row = ix.centroids + (uint64_t)ix.children[cb + (act ? c : 0)] * D;
+        float4 y[RCH > 0 ? RCH : 1];
+        float nb = 0.f;
+        if (RCH > 0) {
+#pragma unroll
+            for (int t = 0; t < RCH; ++t) y[t] = (uint32_t)t < nblk ? ld4(row + 4 * sub + 16 * t, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ix.metric == kMetricCosine) nb = sqrtf(neon16_group4<false>(row, row, D, sub, vec));
+        }
+        for (uint32_t t0 = 0; t0 < np; t0 += kGroupNQ) {
+            __syncthreads(); // pk ready (first pass) / previous tile consumed
+            for (uint32_t j = 0; j < kGroupNQ; ++j) {
+                const float *qg = queries + (uint64_t)(pk[min(t0 + j, np - 1)] >> kPairOffBits) * D;
+                for (uint32_t i = tid; i < D; i += blockDim.x) qs[j * Dp + i] = qg[i];
+            }
+            __syncthreads();
+            float d[kGroupNQ];
+            if (RCH > 0) {
+                float4 acc[kGroupNQ];
+#pragma unroll
+                for (int j = 0; j < kGroupNQ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool l2 = ix.metric == kMetricL2;
+#pragma unroll
+                for (int t = 0; t < RCH; ++t) {
+                    if ((uint32_t)t < nblk) {
+#pragma unroll
+                        for (int j = 0; j < kGroupNQ; ++j) {
+                            const float4 x = ld4(qs + (uint32_t)j * Dp + 4 * sub + 16 * t, vec);
+                            if (l2) {
+                                const float d0 = x.x - y[t].x, d1 = x.y - y[t].y, d2 = x.z - y[t].z, d3 = x.w - y[t].w;
+                                acc[j].x = __builtin_fmaf(d0, d0, acc[j].x);
+                                acc[j].y = __builtin_fmaf(d1, d1, acc[j].y);
+                                acc[j].z = __builtin_fmaf(d2, d2, acc[j].z);
+                                acc[j].w = __builtin_fmaf(d3, d3, acc[j].w);
+                            } else {
+                                acc[j].x = __builtin_fmaf(x.x, y[t].x, acc[j].x);
+                                acc[j].y = __builtin_fmaf(x.y, y[t].y, acc[j].y);
+                                acc[j].z = __builtin_fmaf(x.z, y[t].z, acc[j].z);
+                                acc[j].w = __builtin_fmaf(x.w, y[t].w, acc[j].w);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kGroupNQ; ++j) {
+                    float4 a = acc[j];
+                    a.x += __shfl_xor(a.x, 1, 64); a.y += __shfl_xor(a.y, 1, 64);
+                    a.z += __shfl_xor(a.z, 1, 64); a.w += __shfl_xor(a.w, 1, 64);
+                    a.x += __shfl_xor(a.x, 2, 64); a.y += __shfl_xor(a.y, 2, 64);
+                    a.z += __shfl_xor(a.z, 2, 64); a.w += __shfl_xor(a.w, 2, 64);
+                    const float r = (a.x + a.y) + (a.z + a.w);
+                    const float *qa = qs + (uint32_t)j * Dp;
+                    if (l2) {
+                        d[j] = neon_tail<true>(r, qa, row, nblk << 4, D);
+                    } else {
+                        const float dot = neon_tail<false>(r, qa, row, nblk << 4, D);
+                        if (ix.metric == kMetricDot) {
+                            d[j] = -dot;
+                        } else {
+                            const float na = sqrtf(neon16_group4<false>(qa, qa, D, sub, vec));
+                            d[j] = 1.0f - (dot / (na * nb));
+                        }
+                    }
+                }
+            } else {
+                // any dimension: the accumulators stay in registers while the row slice goes by in
+                // segments of 8 chunks (8 loads in flight per lane)
+                float4 acc[kGroupNQ];
+#pragma unroll
+                for (int j = 0; j < kGroupNQ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool l2 = ix.metric == kMetricL2;
+                for (uint32_t s0 = 0; s0 < nblk; s0 += 8) {
+                    float4 ys[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) ys[t] = s0 + t < nblk ? ld4(row + 4 * sub + 16 * (s0 + t), vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        if (s0 + t < nblk) {
+#pragma unroll
+                            for (int j = 0; j < kGroupNQ; ++j) {
+                                const float4 x = ld4(qs + (uint32_t)j * Dp + 4 * sub + 16 * (s0 + t), vec);
+                                if (l2) {
+                                    const float d0 = x.x - ys[t].x, d1 = x.y - ys[t].y, d2 = x.z - ys[t].z, d3 = x.w - ys[t].w;
+                                    acc[j].x = __builtin_fmaf(d0, d0, acc[j].x);
+                                    acc[j].y = __builtin_fmaf(d1, d1, acc[j].y);
+                                    acc[j].z = __builtin_fmaf(d2, d2, acc[j].z);
+                                    acc[j].w = __builtin_fmaf(d3, d3, acc[j].w);
+                                } else {
+                                    acc[j].x = __builtin_fmaf(x.x, ys[t].x, acc[j].x);
+                                    acc[j].y = __builtin_fmaf(x.y, ys[t].y, acc[j].y);
+                                    acc[j].z = __builtin_fmaf(x.z, ys[t].z, acc[j].z);
+                                    acc[j].w = __builtin_fmaf(x.w, ys[t].w, acc[j].w);
+                                }
+                            }
+                        }
+                    }
+                }
+                if (ix.metric == kMetricCosine && t0 == 0) nb = sqrtf(neon16_group4<false>(row, row, D, sub, vec));
+#pragma unroll
+                for (int j = 0; j < kGroupNQ; ++j) {
+                    float4 a = acc[j];
+                    a.x += __shfl_xor(a.x, 1, 64); a.y += __shfl_xor(a.y, 1, 64);
+                    a.z += __shfl_xor(a.z, 1, 64); a.w += __shfl_xor(a.w, 1, 64);
+                    a.x += __shfl_xor(a.x, 2, 64); a.y += __shfl_xor(a.y, 2, 64);
+                    a.z += __shfl_xor(a.z, 2, 64); a.w += __shfl_xor(a.w, 2, 64);
+                    const float r = (a.x + a.y) + (a.z + a.w);
+                    const float *qa = qs + (uint32_t)j * Dp;
+                    if (l2) {
+                        d[j] = neon_tail<true>(r, qa, row, nblk << 4, D);
+                    } else {
+                        const float dot = neon_tail<false>(r, qa, row, nblk << 4, D);
+                        if (ix.metric == kMetricDot) {
+                            d[j] = -dot;
+                        } else {
+                            const float na = sqrtf(neon16_group4<false>(qa, qa, D, sub, vec));
+                            d[j] = 1.0f - (dot / (na * nb));
+                        }
+                    }
+                }
+            }
+            if (act && sub == 0) {
+#pragma unroll
+                for (int j = 0; j < kGroupNQ; ++j) {
+                    const uint32_t e = pk[min(t0 + j, np - 1)], off = (e & ((1u << kPairOffBits) - 1)) + c;
+                    if (t0 + j < np && off < fstride) fdist[(uint64_t)(e >> kPairOffBits) * fstride + off] = d[j];
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -438,26 +832,27 @@ route_prefilter_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_
     if (threadIdx.x == 0) cand_max[q] = f32_from_key(T);
 }
 
-constexpr int kPrefKpt = 32, kPrefThreads = 512; // register-resident prefilter: n <= 32 * 512
+constexpr int kPrefKpt = 32; // register-resident prefilter: n <= 32 * THREADS
 
-// Same result as route_prefilter_kernel for levels of at most kPrefKpt * kPrefThreads nodes, with
+// Same result as route_prefilter_kernel for levels of at most kPrefKpt * THREADS nodes, with
 // the keys read once and kept in registers: block min/max first (radix passes whose digit is the
 // same for every key are skipped: no counting, no same-address atomics), then the remaining
 // passes from registers; the winners are written in any order (which ties at the threshold are
 // kept is free: every unselected node still has d~ >= cand_max, which is all the proof needs).
-__global__ void __launch_bounds__(kPrefThreads)
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
 route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_t kc, uint32_t *cand_pos,
                            uint32_t cstride, float *cand_max) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t misc[4];
-    __shared__ uint32_t wred[2 * (kPrefThreads / 64)];
+    __shared__ uint32_t wred[2 * (THREADS / 64)];
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float *fd = fdist + (uint64_t)q * fstride;
     uint32_t keys[kPrefKpt];
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
     for (int t = 0; t < kPrefKpt; ++t) {
-        const uint32_t i = t * kPrefThreads + tid;
+        const uint32_t i = t * THREADS + tid;
         keys[t] = i < n ? f32_key(fd[i]) : 0xFFFFFFFFu;
         if (i < n) {
             kmin = min(kmin, keys[t]);
@@ -471,13 +866,13 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
     }
     if (lane == 0) {
         wred[w] = kmin;
-        wred[kPrefThreads / 64 + w] = kmax;
+        wred[THREADS / 64 + w] = kmax;
     }
     if (tid < 2) misc[2 + tid] = 0; // winner counters
     __syncthreads();
-    for (uint32_t v = 0; v < kPrefThreads / 64; ++v) {
+    for (uint32_t v = 0; v < THREADS / 64; ++v) {
         kmin = min(kmin, wred[v]);
-        kmax = max(kmax, wred[kPrefThreads / 64 + v]);
+        kmax = max(kmax, wred[THREADS / 64 + v]);
     }
     uint32_t prefix = 0, want = kc;
     for (int shift = 24; shift >= 0; shift -= 8) {
@@ -485,12 +880,12 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
             prefix |= ((kmin >> shift) & 255u) << shift;
             continue;
         }
-        for (uint32_t i = tid; i < 256; i += kPrefThreads) hist[i] = 0;
+        for (uint32_t i = tid; i < 256; i += THREADS) hist[i] = 0;
         __syncthreads();
         const uint32_t himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
 #pragma unroll
         for (int t = 0; t < kPrefKpt; ++t) {
-            const uint32_t i = t * kPrefThreads + tid;
+            const uint32_t i = t * THREADS + tid;
             if (i < n && (keys[t] & himask) == prefix) atomicAdd(&hist[(keys[t] >> shift) & 255u], 1u);
         }
         __syncthreads();
@@ -518,7 +913,7 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
     uint32_t *cp = cand_pos + (uint64_t)q * cstride;
 #pragma unroll
     for (int t = 0; t < kPrefKpt; ++t) {
-        const uint32_t i = t * kPrefThreads + tid;
+        const uint32_t i = t * THREADS + tid;
         if (i < n) {
             if (keys[t] < T) {
                 const uint32_t slot = atomicAdd(&misc[2], 1u);
@@ -564,7 +959,7 @@ __global__ void __launch_bounds__(256)
 route_finish_kernel(IndexDev ix, const uint32_t *level_nodes, uint32_t n, const uint32_t *cand_pos,
                     const float *cand_dist, uint32_t cstride, uint32_t kc, const float *cand_max, const float *qsq,
                     float max_csq, uint32_t probes, uint32_t *next_frontier, uint32_t fstride, uint32_t *next_fcount,
-                    uint32_t *leaves, uint32_t lstride, uint32_t *lcount, uint32_t *flag, uint32_t *fallbacks) {
+                    uint32_t *leaves, uint32_t lstride, uint32_t *lcount, uint32_t *flag, uint32_t *fallbacks, PairOut po) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t kpad = next_pow2(kc);
     uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);
@@ -588,7 +983,7 @@ route_finish_kernel(IndexDev ix, const uint32_t *level_nodes, uint32_t n, const 
     }
     if (tid == 0) flag[q] = 0;
     route_expand(ix, level_nodes, skeys, probes, cnt_leaf, cnt_child, next_frontier + (uint64_t)q * fstride, fstride,
-                 next_fcount + q, leaves + (uint64_t)q * lstride, lstride, lcount + q);
+                 next_fcount + q, leaves + (uint64_t)q * lstride, lstride, lcount + q, po, q);
 }
 
 } // namespace cuddle
