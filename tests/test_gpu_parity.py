@@ -103,7 +103,8 @@ def test_mfma_routing_is_exact(gpu, metric):
     _compare_full(fi, dev, q[:40], 10, probes, 5)
 
 
-@pytest.mark.parametrize("metric,d", [("l2", 64), ("cosine", 48), ("dot", 37), ("l2", 200), ("cosine", 272), ("dot", 300)])
+@pytest.mark.parametrize("metric,d", [("l2", 64), ("cosine", 48), ("dot", 37), ("l2", 200), ("cosine", 272), ("dot", 300),
+                                      ("cosine", 128), ("dot", 96), ("l2", 256)])
 def test_grouped_routing_is_exact(gpu, metric, d):
     """Three levels: the roots are cut to `probes`, so the second level's frontier differs per query
     and (being wider than 100 nodes) is evaluated grouped by parent; leaf lists must equal the

@@ -173,6 +173,28 @@ static constexpr uint32_t kScanThreads = 512;
 static constexpr uint32_t kGemmMinWidth = 512; // narrower levels are routed by the exact kernel
 static constexpr uint32_t kLdsDistCap = 24576; // u16 distances kept in LDS per query (48 KiB)
 
+using GroupedKernel = void (*)(IndexDev, const float *, const uint32_t *, uint32_t, const uint32_t *, const uint4 *,
+                               const uint32_t *, float *, uint32_t);
+
+template <int NBLK>
+static GroupedKernel grouped_kernel_metric(uint32_t metric) {
+    if (metric == CUDDLE_METRIC_L2) return route_dist_grouped_kernel<NBLK, kMetricL2>;
+    if (metric == CUDDLE_METRIC_DOT) return route_dist_grouped_kernel<NBLK, kMetricDot>;
+    return route_dist_grouped_kernel<NBLK, kMetricCosine>;
+}
+
+// The grouped routing kernel for an index: centroid slices held in registers for the common
+// dimensions, the any-dimension variant otherwise.
+static GroupedKernel grouped_kernel_for(uint32_t dim, uint32_t metric) {
+    switch (dim) {
+    case 64: return grouped_kernel_metric<4>(metric);
+    case 96: return grouped_kernel_metric<6>(metric);
+    case 128: return grouped_kernel_metric<8>(metric);
+    case 256: return grouped_kernel_metric<16>(metric);
+    default: return grouped_kernel_metric<0>(metric);
+    }
+}
+
 using ScanKernel = void (*)(IndexDev, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, uint32_t,
                             uint32_t, uint32_t, void *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *,
                             const uint32_t *);
@@ -502,7 +524,7 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     (void)hipFuncSetAttribute((const void *)route_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)route_dist_grouped_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)grouped_kernel_for(v.dim, v.metric), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_select_rabitq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_all_rabitq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -605,7 +627,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     const size_t gw = (size_t)ix->max_parent_width + 1;
     size_t o_pi = carve(qc * pl.probes * 4), o_pp = carve(qc * pl.probes * 4), o_ps = carve(qc * pl.probes * 4);
     size_t o_sf = carve(qc * 4), o_gc = carve(gw * 4), o_gp = carve(gw * 4), o_gi = carve(gw * 4), o_gf = carve(gw * 4);
-    size_t o_git = carve((qc * pl.probes / kGroupPairs + gw + 1) * 4);
+    size_t o_git = carve((qc * pl.probes / kGroupPairs + gw + 1) * 16);
     pl.bytes = off;
     ST_TRY(ix->ws.ensure(pl.bytes));
     char *b = static_cast<char *>(ix->ws.p);
@@ -694,7 +716,9 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         fb = std::min<uint64_t>(fb, ix->level_width[l]);
         const uint32_t bound = (uint32_t)std::max<uint64_t>(fb, 1);
         const bool keep_all = !stats && bound <= pl.probes;
-        const uint32_t scap = std::min(kSortCap, host_next_pow2(bound));
+        // frontiers of up to scap nodes are sorted whole, larger ones are cut to probes first: scap
+        // only has to hold probes, and a small one keeps the selection kernels' LDS footprint low
+        const uint32_t scap = std::min(std::min(kSortCap, host_next_pow2(bound)), std::max(512u, host_next_pow2(pl.probes)));
         const LevelGemm &g = ix->lvl[l];
         const uint32_t *sfr = shared ? g.nodes : nullptr;
         const uint32_t sn = shared ? ix->level_width[l] : 0;
@@ -710,14 +734,14 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             // pairs recorded by the level above -> parent order -> one block per (parent, 8 queries)
             const uint32_t wprev = ix->level_width[l - 1], total = nq * pl.probes;
             hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, pl.grp_cnt, wprev, pl.grp_poff, pl.grp_ioff, pl.grp_fill,
-                               pl.grp_item);
+                               reinterpret_cast<uint4 *>(pl.grp_item));
             hipLaunchKernelGGL(pair_fill_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pl.pair_info, pl.pair_parent, total,
                                pl.grp_poff, pl.grp_fill, pl.pair_sorted);
             const uint32_t items = (total + kGroupPairs - 1) / kGroupPairs + std::min(wprev, total);
-            const size_t glds = (size_t)kGroupNQ * ((v.dim + 3) & ~3u) * sizeof(float);
-            auto gk = v.dim <= 128 ? route_dist_grouped_kernel<8> : v.dim <= 256 ? route_dist_grouped_kernel<16> : route_dist_grouped_kernel<0>;
-            hipLaunchKernelGGL(gk, dim3(items), dim3(256), glds, s, v, dq, ix->lvl[l - 1].nodes, wprev, pl.grp_poff, pl.grp_ioff,
-                               pl.grp_item, pl.pair_sorted, pl.fdist, pl.fstride);
+            const size_t glds = 2 * (size_t)kGroupNQ * ((v.dim + 3) & ~3u) * sizeof(float);
+            auto gk = grouped_kernel_for(v.dim, v.metric);
+            hipLaunchKernelGGL(gk, dim3(items), dim3(256), glds, s, v, dq, ix->lvl[l - 1].nodes, wprev, pl.grp_ioff,
+                               reinterpret_cast<const uint4 *>(pl.grp_item), pl.pair_sorted, pl.fdist, pl.fstride);
             only = pl.small_flag; // queries with small frontiers: the exact kernel below, in their own arithmetic
         }
         // Will the next level evaluate per-query frontiers wider than probes? Then this level's
@@ -798,6 +822,12 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
 }
+
+#ifdef CUDDLE_GROUP_TIMING
+extern "C" int cuddle_debug_group_times(uint64_t *out, uint32_t n_blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_group_stamps), (size_t)std::min(n_blocks, 16384u) * 32);
+}
+#endif
 
 #ifdef CUDDLE_SCAN_TIMING
 static void *g_scan_stamps = nullptr;

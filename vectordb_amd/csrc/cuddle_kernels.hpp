@@ -306,6 +306,23 @@ __device__ __forceinline__ void chunked_threshold_select(const DistT *dist, uint
 // exact distances in the reference's accumulation order
 // ---------------------------------------------------------------------------------------------
 
+// Value of the lane whose number differs in bit 0 / bit 1 (the other lanes of a 4-lane group),
+// as a DPP quad permutation: no LDS round trip, and the compiler can fold it into the add.
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
+}
+
+// (sum0+sum1)+(sum2+sum3) over the four lanes' accumulators, lane-wise, then the pairwise
+// horizontal add (u0+u1)+(u2+u3): every lane of the group returns the same value.
+__device__ __forceinline__ float group4_reduce(float4 a) {
+    a.x += quad_xor1(a.x); a.y += quad_xor1(a.y); a.z += quad_xor1(a.z); a.w += quad_xor1(a.w);
+    a.x += quad_xor2(a.x); a.y += quad_xor2(a.y); a.z += quad_xor2(a.z); a.w += quad_xor2(a.w);
+    return (a.x + a.y) + (a.z + a.w);
+}
+
 __device__ __forceinline__ float4 ld4(const float *p, bool vec) {
     if (vec) return *reinterpret_cast<const float4 *>(p);
     return make_float4(p[0], p[1], p[2], p[3]);
@@ -363,12 +380,7 @@ __device__ __forceinline__ float neon16_group4(const float *a, const float *b, u
             acc.w = __builtin_fmaf(x.w, y.w, acc.w);
         }
     }
-    acc.x += __shfl_xor(acc.x, 1, 64); acc.y += __shfl_xor(acc.y, 1, 64);
-    acc.z += __shfl_xor(acc.z, 1, 64); acc.w += __shfl_xor(acc.w, 1, 64);
-    acc.x += __shfl_xor(acc.x, 2, 64); acc.y += __shfl_xor(acc.y, 2, 64);
-    acc.z += __shfl_xor(acc.z, 2, 64); acc.w += __shfl_xor(acc.w, 2, 64);
-    float r = (acc.x + acc.y) + (acc.z + acc.w);
-    return neon_tail<L2>(r, a, b, nblk << 4, n);
+    return neon_tail<L2>(group4_reduce(acc), a, b, nblk << 4, n);
 }
 
 // The same routines computed by one lane (16 running partial sums).
@@ -461,13 +473,7 @@ __device__ __forceinline__ void neon16_group4_multi(const float *qs, uint32_t qs
     }
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-        float4 a = acc[j];
-        a.x += __shfl_xor(a.x, 1, 64); a.y += __shfl_xor(a.y, 1, 64);
-        a.z += __shfl_xor(a.z, 1, 64); a.w += __shfl_xor(a.w, 1, 64);
-        a.x += __shfl_xor(a.x, 2, 64); a.y += __shfl_xor(a.y, 2, 64);
-        a.z += __shfl_xor(a.z, 2, 64); a.w += __shfl_xor(a.w, 2, 64);
-        const float r = (a.x + a.y) + (a.z + a.w);
-        out[j] = neon_tail<L2>(r, qs + (uint32_t)j * qstride, b, nblk << 4, n);
+        out[j] = neon_tail<L2>(group4_reduce(acc[j]), qs + (uint32_t)j * qstride, b, nblk << 4, n);
     }
 }
 

@@ -85,6 +85,7 @@ struct PairOut {
 constexpr uint32_t kPairOffBits = 20; // next-frontier positions below 2^20, queries per chunk below 2^12
 constexpr int kGroupNQ = 8;           // queries per tile of route_dist_grouped_kernel
 constexpr int kGroupPairs = 64;       // pairs per block of route_dist_grouped_kernel (8 tiles)
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Split the chosen nodes into leaves and internal nodes (hierarchical.rs:411-413), append the
 // leaves to the query's leaf list (:416) and write the children of the internal nodes, in order,
@@ -428,10 +429,10 @@ route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride,
 // smaller frontiers are not grouped (PairOut::small).
 
 // Exclusive prefix sums over the per-parent pair counts: poff = pairs, ioff = work items (blocks of
-// up to kGroupPairs pairs of one parent); item_parent[item] = its parent; also clears the fill
-// counters. One block of 1024 threads; the per-parent arrays hold n + 1 entries.
+// up to kGroupPairs pairs of one parent); items[item] = (parent, first pair, pairs, 0); also clears
+// the fill counters. One block of 1024 threads; the per-parent arrays hold n + 1 entries.
 __global__ void __launch_bounds__(1024)
-pair_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *poff, uint32_t *ioff, uint32_t *fill, uint32_t *item_parent) {
+pair_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *poff, uint32_t *ioff, uint32_t *fill, uint4 *items) {
     __shared__ uint32_t sp[1024], si[1024];
     const uint32_t tid = threadIdx.x, per = (n + 1023) / 1024;
     const uint32_t b = min(tid * per, n), e = min(b + per, n);
@@ -456,7 +457,8 @@ pair_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *poff, uint32_t *ioff
         poff[i] = rp;
         ioff[i] = ri;
         fill[i] = 0;
-        for (uint32_t t = 0; t < ni; ++t) item_parent[ri + t] = i;
+        for (uint32_t t = 0; t < ni; ++t)
+            items[ri + t] = make_uint4(i, rp + t * kGroupPairs, min((uint32_t)kGroupPairs, c - t * kGroupPairs), 0u);
         rp += c;
         ri += ni;
     }
@@ -478,159 +480,192 @@ __global__ void pair_fill_kernel(const uint32_t *info, const uint32_t *parent, u
 }
 
 // One block per work item = (parent, up to kGroupPairs of its pairs); blocks past the last item
-// exit. block = 256: one 4-lane group per child (64 children per pass) keeps its slice of the
-// child's centroid in registers (RCH chunks of 16 dimensions, dim <= 16 * RCH; RCH = 0: any dim,
-// the slice is re-read in segments of 8 chunks for every tile) while the item's pairs go by in
-// tiles of kGroupNQ queries staged in LDS.
-// dynamic LDS = kGroupNQ * pad4(dim) floats.
-template <int RCH>
-__global__ void __launch_bounds__(256)
+// exit. block = 256: one 4-lane group per child (64 children per pass).
+//   NBLK > 0: dim == 16 * NBLK. The group keeps its slice of the child's centroid in registers
+//     while the item's pairs go by in tiles of kGroupNQ queries staged in LDS; the next tile's
+//     queries are fetched into registers while the current tile is evaluated (two LDS buffers, one
+//     barrier per tile), four queries at a time to bound the accumulator registers.
+//   NBLK == 0: any dim. The slice is re-read in segments of 8 chunks for every tile.
+// METRIC is the index metric. dynamic LDS = 2 * kGroupNQ * pad4(dim) floats.
+#ifdef CUDDLE_GROUP_TIMING // debug builds: 100 MHz clock stamps per block (start, rows loaded, first tile staged, end)
+__device__ uint64_t g_group_stamps[16384 * 4];
+#define CUDDLE_GSTAMP(n)                                                                          \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < 16384) g_group_stamps[blockIdx.x * 4 + (n)] = wall_clock64(); \
+    } while (0)
+#else
+#define CUDDLE_GSTAMP(n) do { } while (0)
+#endif
+
+template <int NBLK, uint32_t METRIC>
+__global__ void __launch_bounds__(256, NBLK > 8 ? 2 : 4) // waves per SIMD the register allocation must allow
 route_dist_grouped_kernel(IndexDev ix, const float *queries, const uint32_t *level_nodes, uint32_t n_parents,
-                          const uint32_t *poff, const uint32_t *ioff, const uint32_t *item_parent,
-                          const uint32_t *sorted, float *fdist, uint32_t fstride) {
+                          const uint32_t *ioff, const uint4 *items, const uint32_t *sorted, float *fdist,
+                          uint32_t fstride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *qs = reinterpret_cast<float *>(smem);
+    float *qbuf = reinterpret_cast<float *>(smem);
     __shared__ uint32_t pk[kGroupPairs];
+    constexpr bool L2 = METRIC == kMetricL2;
     const uint32_t item = blockIdx.x;
-    if (item >= ioff[n_parents]) return;
-    const uint32_t p = item_parent[item], D = ix.dim, Dp = (D + 3) & ~3u, tid = threadIdx.x;
-    const uint32_t pb = poff[p] + (item - ioff[p]) * kGroupPairs, np = min((uint32_t)kGroupPairs, poff[p + 1] - pb);
+    const uint32_t n_items = ioff[n_parents];
+    const uint4 rec = items[min(item, max(n_items, 1u) - 1)];
+    if (item >= n_items) return;
+    CUDDLE_GSTAMP(0);
+    const uint32_t p = rec.x, pb = rec.y, np = rec.z;
+    const uint32_t D = NBLK > 0 ? 16u * NBLK : ix.dim, Dp = (D + 3) & ~3u, tid = threadIdx.x;
     if (tid < kGroupPairs) pk[tid] = sorted[pb + min(tid, np - 1)]; // unused slots repeat the last pair
     const uint32_t node = level_nodes[p];
     const uint32_t cb = ix.child_off[node], cc = ix.child_off[node + 1] - cb;
     const uint32_t sub = tid & 3, nblk = D >> 4;
-    const bool vec = (D & 3) == 0;
+    const bool vec = NBLK > 0 || (D & 3) == 0;
+    constexpr int PF = NBLK > 0 ? (NBLK + 7) / 8 : 1; // float4 per thread and tile: kGroupNQ * 4 * NBLK / 256
+    constexpr uint32_t d4 = NBLK > 0 ? 4u * NBLK : 1u; // float4 per query
     for (uint32_t c0 = 0; c0 < cc; c0 += 64) { // block-uniform trip counts throughout
         const uint32_t c = c0 + (tid >> 2);
         const bool act = c < cc;
         const float *row = ix.centroids + (uint64_t)ix.children[cb + (act ? c : 0)] * D;
-        float4 y[RCH > 0 ? RCH : 1];
+        float4 y[NBLK > 0 ? NBLK : 1];
         float nb = 0.f;
-        if (RCH > 0) {
+        if (NBLK > 0) {
 #pragma unroll
-            for (int t = 0; t < RCH; ++t) y[t] = (uint32_t)t < nblk ? ld4(row + 4 * sub + 16 * t, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ix.metric == kMetricCosine) nb = sqrtf(neon16_group4<false>(row, row, D, sub, vec));
+            for (int t = 0; t < NBLK; ++t) y[t] = *reinterpret_cast<const float4 *>(row + 4 * sub + 16 * t);
         }
-        for (uint32_t t0 = 0; t0 < np; t0 += kGroupNQ) {
-            __syncthreads(); // pk ready (first pass) / previous tile consumed
-            for (uint32_t j = 0; j < kGroupNQ; ++j) {
-                const float *qg = queries + (uint64_t)(pk[min(t0 + j, np - 1)] >> kPairOffBits) * D;
-                for (uint32_t i = tid; i < D; i += blockDim.x) qs[j * Dp + i] = qg[i];
+        if (METRIC == kMetricCosine) nb = sqrtf(neon16_group4<false>(row, row, D, sub, vec));
+#ifdef CUDDLE_GROUP_TIMING
+        if (NBLK > 0 && y[0].x == 12345.678f) nb = 1.f; // wait for the rows before the stamp
+#endif
+        CUDDLE_GSTAMP(1);
+        __syncthreads(); // pk ready (first pass) / last tile of the previous pass consumed
+        float4 pf[PF];
+        // queries of tile t0 -> registers: float4 number f of the tile = tid + 256 k
+        auto fetch = [&](uint32_t t0) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const uint32_t f = tid + 256 * k, j = f / d4, e = f - j * d4;
+                pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j < kGroupNQ)
+                    pf[k] = *reinterpret_cast<const float4 *>(queries + (uint64_t)(pk[min(t0 + j, np - 1)] >> kPairOffBits) * D + 4 * e);
             }
+        };
+        auto stash = [&](float *qs) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const uint32_t f = tid + 256 * k, j = f / d4, e = f - j * d4;
+                if (j < kGroupNQ) *reinterpret_cast<float4 *>(qs + j * Dp + 4 * e) = pf[k];
+            }
+        };
+        if (NBLK > 0) {
+            fetch(0);
+            stash(qbuf);
             __syncthreads();
-            float d[kGroupNQ];
-            if (RCH > 0) {
-                float4 acc[kGroupNQ];
-#pragma unroll
-                for (int j = 0; j < kGroupNQ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                const bool l2 = ix.metric == kMetricL2;
-#pragma unroll
-                for (int t = 0; t < RCH; ++t) {
-                    if ((uint32_t)t < nblk) {
-#pragma unroll
-                        for (int j = 0; j < kGroupNQ; ++j) {
-                            const float4 x = ld4(qs + (uint32_t)j * Dp + 4 * sub + 16 * t, vec);
-                            if (l2) {
-                                const float d0 = x.x - y[t].x, d1 = x.y - y[t].y, d2 = x.z - y[t].z, d3 = x.w - y[t].w;
-                                acc[j].x = __builtin_fmaf(d0, d0, acc[j].x);
-                                acc[j].y = __builtin_fmaf(d1, d1, acc[j].y);
-                                acc[j].z = __builtin_fmaf(d2, d2, acc[j].z);
-                                acc[j].w = __builtin_fmaf(d3, d3, acc[j].w);
-                            } else {
-                                acc[j].x = __builtin_fmaf(x.x, y[t].x, acc[j].x);
-                                acc[j].y = __builtin_fmaf(x.y, y[t].y, acc[j].y);
-                                acc[j].z = __builtin_fmaf(x.z, y[t].z, acc[j].z);
-                                acc[j].w = __builtin_fmaf(x.w, y[t].w, acc[j].w);
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < kGroupNQ; ++j) {
-                    float4 a = acc[j];
-                    a.x += __shfl_xor(a.x, 1, 64); a.y += __shfl_xor(a.y, 1, 64);
-                    a.z += __shfl_xor(a.z, 1, 64); a.w += __shfl_xor(a.w, 1, 64);
-                    a.x += __shfl_xor(a.x, 2, 64); a.y += __shfl_xor(a.y, 2, 64);
-                    a.z += __shfl_xor(a.z, 2, 64); a.w += __shfl_xor(a.w, 2, 64);
-                    const float r = (a.x + a.y) + (a.z + a.w);
-                    const float *qa = qs + (uint32_t)j * Dp;
-                    if (l2) {
-                        d[j] = neon_tail<true>(r, qa, row, nblk << 4, D);
-                    } else {
-                        const float dot = neon_tail<false>(r, qa, row, nblk << 4, D);
-                        if (ix.metric == kMetricDot) {
-                            d[j] = -dot;
-                        } else {
-                            const float na = sqrtf(neon16_group4<false>(qa, qa, D, sub, vec));
-                            d[j] = 1.0f - (dot / (na * nb));
-                        }
-                    }
-                }
+        }
+        CUDDLE_GSTAMP(2);
+        for (uint32_t t0 = 0, it = 0; t0 < np; t0 += kGroupNQ, ++it) {
+            float *qs = qbuf + (NBLK > 0 ? (it & 1) * kGroupNQ * Dp : 0);
+            if (NBLK > 0) {
+                if (t0 + kGroupNQ < np) fetch(t0 + kGroupNQ);
             } else {
-                // any dimension: the accumulators stay in registers while the row slice goes by in
-                // segments of 8 chunks (8 loads in flight per lane)
-                float4 acc[kGroupNQ];
+                if (it) __syncthreads(); // previous tile consumed
+                for (uint32_t j = 0; j < kGroupNQ; ++j) {
+                    const float *qg = queries + (uint64_t)(pk[min(t0 + j, np - 1)] >> kPairOffBits) * D;
+                    for (uint32_t i = tid; i < D; i += blockDim.x) qs[j * Dp + i] = qg[i];
+                }
+                __syncthreads();
+            }
+            float dres[kGroupNQ];
 #pragma unroll
-                for (int j = 0; j < kGroupNQ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                const bool l2 = ix.metric == kMetricL2;
-                for (uint32_t s0 = 0; s0 < nblk; s0 += 8) {
-                    float4 ys[8];
+            for (uint32_t jh = 0; jh < kGroupNQ; jh += 4) { // four queries at a time
+                __builtin_amdgcn_sched_barrier(0);
+                // two-float vector arithmetic = the packed f32 instructions; each component is the
+                // same IEEE operation as the scalar form
+                v2f acc_lo[4], acc_hi[4];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) ys[t] = s0 + t < nblk ? ld4(row + 4 * sub + 16 * (s0 + t), vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int j = 0; j < 4; ++j) acc_lo[j] = acc_hi[j] = v2f{0.f, 0.f};
+                const float *qh = qs + jh * Dp + 4 * sub;
+                auto load_x = [&](float4 *x, uint32_t t) {
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        if (s0 + t < nblk) {
+                    for (int j = 0; j < 4; ++j) x[j] = ld4(qh + (uint32_t)j * Dp + 16 * t, vec);
+                };
+                auto step = [&](const float4 &yy, const float4 *x) {
+                    const v2f ylo{yy.x, yy.y}, yhi{yy.z, yy.w};
 #pragma unroll
-                            for (int j = 0; j < kGroupNQ; ++j) {
-                                const float4 x = ld4(qs + (uint32_t)j * Dp + 4 * sub + 16 * (s0 + t), vec);
-                                if (l2) {
-                                    const float d0 = x.x - ys[t].x, d1 = x.y - ys[t].y, d2 = x.z - ys[t].z, d3 = x.w - ys[t].w;
-                                    acc[j].x = __builtin_fmaf(d0, d0, acc[j].x);
-                                    acc[j].y = __builtin_fmaf(d1, d1, acc[j].y);
-                                    acc[j].z = __builtin_fmaf(d2, d2, acc[j].z);
-                                    acc[j].w = __builtin_fmaf(d3, d3, acc[j].w);
-                                } else {
-                                    acc[j].x = __builtin_fmaf(x.x, ys[t].x, acc[j].x);
-                                    acc[j].y = __builtin_fmaf(x.y, ys[t].y, acc[j].y);
-                                    acc[j].z = __builtin_fmaf(x.z, ys[t].z, acc[j].z);
-                                    acc[j].w = __builtin_fmaf(x.w, ys[t].w, acc[j].w);
-                                }
-                            }
+                    for (int j = 0; j < 4; ++j) {
+                        const v2f xlo{x[j].x, x[j].y}, xhi{x[j].z, x[j].w};
+                        if (L2) {
+                            const v2f dlo = xlo - ylo, dhi = xhi - yhi;
+                            acc_lo[j] = __builtin_elementwise_fma(dlo, dlo, acc_lo[j]);
+                            acc_hi[j] = __builtin_elementwise_fma(dhi, dhi, acc_hi[j]);
+                        } else {
+                            acc_lo[j] = __builtin_elementwise_fma(xlo, ylo, acc_lo[j]);
+                            acc_hi[j] = __builtin_elementwise_fma(xhi, yhi, acc_hi[j]);
                         }
                     }
-                }
-                if (ix.metric == kMetricCosine && t0 == 0) nb = sqrtf(neon16_group4<false>(row, row, D, sub, vec));
+                };
+                if (NBLK > 0) {
+                    // the queries of chunk t + 1 are read from LDS while chunk t is evaluated; the
+                    // scheduling barrier keeps the compiler from hoisting every read to the top
+                    float4 xc[4], xn[4];
+                    load_x(xc, 0);
 #pragma unroll
-                for (int j = 0; j < kGroupNQ; ++j) {
-                    float4 a = acc[j];
-                    a.x += __shfl_xor(a.x, 1, 64); a.y += __shfl_xor(a.y, 1, 64);
-                    a.z += __shfl_xor(a.z, 1, 64); a.w += __shfl_xor(a.w, 1, 64);
-                    a.x += __shfl_xor(a.x, 2, 64); a.y += __shfl_xor(a.y, 2, 64);
-                    a.z += __shfl_xor(a.z, 2, 64); a.w += __shfl_xor(a.w, 2, 64);
-                    const float r = (a.x + a.y) + (a.z + a.w);
-                    const float *qa = qs + (uint32_t)j * Dp;
-                    if (l2) {
-                        d[j] = neon_tail<true>(r, qa, row, nblk << 4, D);
+                    for (int t = 0; t < NBLK; ++t) {
+                        if (t + 1 < NBLK) load_x(xn, t + 1);
+                        step(y[t], xc);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xc[j] = xn[j];
+                    }
+                } else {
+                    for (uint32_t s0 = 0; s0 < nblk; s0 += 8) { // 8 row loads in flight per lane
+                        float4 ys[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) ys[t] = s0 + t < nblk ? ld4(row + 4 * sub + 16 * (s0 + t), vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            if (s0 + t < nblk) {
+                                float4 x[4];
+                                load_x(x, s0 + t);
+                                step(ys[t], x);
+                            }
+                    }
+                }
+                float4 acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = make_float4(acc_lo[j].x, acc_lo[j].y, acc_hi[j].x, acc_hi[j].y);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float r = group4_reduce(acc[j]);
+                    const float *qa = qs + (jh + j) * Dp;
+                    float d;
+                    if (L2) {
+                        d = NBLK > 0 ? r : neon_tail<true>(r, qa, row, nblk << 4, D);
                     } else {
-                        const float dot = neon_tail<false>(r, qa, row, nblk << 4, D);
-                        if (ix.metric == kMetricDot) {
-                            d[j] = -dot;
+                        const float dot = NBLK > 0 ? r : neon_tail<false>(r, qa, row, nblk << 4, D);
+                        if (METRIC == kMetricDot) {
+                            d = -dot;
                         } else {
                             const float na = sqrtf(neon16_group4<false>(qa, qa, D, sub, vec));
-                            d[j] = 1.0f - (dot / (na * nb));
+                            d = 1.0f - (dot / (na * nb));
                         }
                     }
+                    dres[jh + j] = d;
                 }
+            }
+            // the next tile's queries go to LDS before this tile's results are stored: waiting for
+            // the fetch must not also wait for the stores to be acknowledged
+            if (NBLK > 0 && t0 + kGroupNQ < np) {
+                stash(qbuf + ((it + 1) & 1) * kGroupNQ * Dp); // that buffer's tile was consumed before the last barrier
+                __syncthreads();
             }
             if (act && sub == 0) {
 #pragma unroll
                 for (int j = 0; j < kGroupNQ; ++j) {
                     const uint32_t e = pk[min(t0 + j, np - 1)], off = (e & ((1u << kPairOffBits) - 1)) + c;
-                    if (t0 + j < np && off < fstride) fdist[(uint64_t)(e >> kPairOffBits) * fstride + off] = d[j];
+                    if (t0 + j < np && off < fstride) fdist[(uint64_t)(e >> kPairOffBits) * fstride + off] = dres[j];
                 }
             }
         }
     }
+    CUDDLE_GSTAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------------
