@@ -1,9 +1,11 @@
-"""Per-phase timing of the Hamming scan kernel's blocks (needs a -DCUDDLE_SCAN_TIMING build of the
-library, selected with CUDDLE_HIP_LIB). Prints the mean duration of each phase of a block and the
-average number of blocks in flight. Development tool; not used by the tests or the benchmark.
+"""Per-phase timing of the blocks of one kernel. Needs a build of the library with
+-DCUDDLE_STAMP_KERNEL=<id> (1 Hamming scan, 2 grouped routing distances, 3 register selection),
+selected with CUDDLE_HIP_LIB; prints the mean time between consecutive stamps of a block, the block
+lifetime and the average number of blocks in flight. Development tool; not used by the tests or
+the benchmark.
 
-    hipcc ... -DCUDDLE_SCAN_TIMING -o vectordb_amd/libcuddle_timing.so vectordb_amd/csrc/cuddle_hip.hip
-    CUDDLE_HIP_LIB=$PWD/vectordb_amd/libcuddle_timing.so python tools/scan_phase_times.py shard12m
+    hipcc ... -DCUDDLE_STAMP_KERNEL=2 -o vectordb_amd/libcuddle_timing.so vectordb_amd/csrc/cuddle_hip.hip
+    CUDDLE_HIP_LIB=$PWD/vectordb_amd/libcuddle_timing.so python tools/kernel_phase_times.py shard12m 25 4
 """
 import ctypes
 import os
@@ -21,6 +23,7 @@ from vectordb_amd import _ffi  # noqa: E402
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "shard12m"
     rf = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+    npts = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     cfg = bench.CONFIGS[name]
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -46,23 +49,19 @@ def main():
     for _ in range(3):
         idx.search_batch_device(queries, k, cfg["probes"], rf, 0, ids, dd, cnt)
     torch.cuda.synchronize()
-    lib = _ffi.lib()
-    fn = lib.cuddle_debug_scan_times
+    fn = _ffi.lib().cuddle_debug_stamps
     fn.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
     fn.restype = ctypes.c_int
-    n = min(nq, 4096)
-    out = np.zeros((n, 8), dtype=np.uint64)
-    assert fn(out.ctypes.data, n) == 0
-    t = out[:, :5].astype(np.int64)
-    t = t[(t[:, 4] > 0)]
+    out = np.zeros((16384, 8), dtype=np.uint64)
+    assert fn(out.ctypes.data, 16384) == 0
+    t = out[:, :npts].astype(np.int64)
+    t = t[(t > 0).all(axis=1)]
     d = np.diff(t, axis=1) * 0.01  # 100 MHz ticks -> microseconds
-    names = ["prologue (leaf tables)", "phase 1 (stream codes)", "phase 2 (threshold)", "phase 3 (compaction)"]
-    for i, nm in enumerate(names):
-        print(f"{nm:28s} mean {d[:, i].mean():8.2f} us   p50 {np.median(d[:, i]):8.2f}   max {d[:, i].max():8.2f}")
-    life = (t[:, 4] - t[:, 0]) * 0.01
-    span = (t[:, 4].max() - t[:, 0].min()) * 0.01
-    print(f"block lifetime mean {life.mean():.2f} us; kernel span {span:.1f} us; blocks in flight (avg) "
-          f"{life.sum() / span:.1f} of {len(t)}")
+    for i in range(npts - 1):
+        print(f"stamp {i} -> {i + 1}: mean {d[:, i].mean():8.2f} us   p50 {np.median(d[:, i]):8.2f}   max {d[:, i].max():8.2f}")
+    life = (t[:, -1] - t[:, 0]) * 0.01
+    span = (t[:, -1].max() - t[:, 0].min()) * 0.01
+    print(f"blocks {len(t)}; lifetime mean {life.mean():.2f} us; span {span:.1f} us; in flight (avg) {life.sum() / span:.1f}")
 
 
 if __name__ == "__main__":

@@ -522,8 +522,11 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     (void)hipFuncSetAttribute((const void *)scan_kernel_for(v.dim, v.words), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_all_hamming_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<256, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<256, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)grouped_kernel_for(v.dim, v.metric), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_select_rabitq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -799,16 +802,23 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             hipLaunchKernelGGL(route_dist_kernel, dim3((use_gemm || grouped) ? 4 : std::min<uint32_t>((bound + 63) / 64, 64), nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                pl.frontier[cur], pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, only);
         const uint32_t *sel_only = grouped ? nullptr : only; // after the grouped path every query still selects here
-        if (!keep_all && bound <= (uint32_t)kSelKpt * 256)
-            hipLaunchKernelGGL(route_select_reg_kernel<256>, dim3(nq), dim3(256), route_select_lds_bytes(scap), s, v, pl.frontier[cur],
-                               pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, scap,
-                               next_shared ? nullptr : pl.frontier[cur ^ 1], pl.fcount[cur ^ 1], pl.leaves, pl.lstride,
-                               pl.lcount, sel_only, po);
-        else if (!keep_all && bound <= (uint32_t)kSelKpt * 512)
-            hipLaunchKernelGGL(route_select_reg_kernel<512>, dim3(nq), dim3(512), route_select_lds_bytes(scap), s, v, pl.frontier[cur],
-                               pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, scap,
-                               next_shared ? nullptr : pl.frontier[cur ^ 1], pl.fcount[cur ^ 1], pl.leaves, pl.lstride,
-                               pl.lcount, sel_only, po);
+#define CUDDLE_SELECT_REG(T, K)                                                                                              \
+    hipLaunchKernelGGL((route_select_reg_kernel<T, K>), dim3(nq), dim3(T), route_select_reg_lds_bytes(scap), s, v, pl.frontier[cur], \
+                       pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, scap,                                    \
+                       next_shared ? nullptr : pl.frontier[cur ^ 1], pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,       \
+                       sel_only, po)
+        // small blocks, as few keys per thread as the level's bound allows: a block's time is mostly
+        // latency (loads, barriers), so what counts is how many of them are in flight
+        if (!keep_all && bound <= 256 * 8)
+            CUDDLE_SELECT_REG(256, 8);
+        else if (!keep_all && bound <= 256 * 16)
+            CUDDLE_SELECT_REG(256, 16);
+        else if (!keep_all && bound <= 256 * 24)
+            CUDDLE_SELECT_REG(256, 24);
+        else if (!keep_all && bound <= 256 * 32)
+            CUDDLE_SELECT_REG(256, 32);
+        else if (!keep_all && bound <= 512 * 32)
+            CUDDLE_SELECT_REG(512, 32);
         else
             hipLaunchKernelGGL(route_select_kernel, dim3(nq), dim3(256), route_select_lds_bytes(scap), s, v, pl.frontier[cur],
                                pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, scap,
@@ -823,26 +833,15 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
     return CUDDLE_OK;
 }
 
-#ifdef CUDDLE_GROUP_TIMING
-extern "C" int cuddle_debug_group_times(uint64_t *out, uint32_t n_blocks) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_group_stamps), (size_t)std::min(n_blocks, 16384u) * 32);
-}
-#endif
-
-#ifdef CUDDLE_SCAN_TIMING
-static void *g_scan_stamps = nullptr;
-extern "C" int cuddle_debug_scan_times(uint64_t *out, uint32_t nq) {
-    if (!g_scan_stamps) return 1;
-    return (int)hipMemcpy(out, g_scan_stamps, (size_t)nq * 64, hipMemcpyDeviceToHost);
+#ifdef CUDDLE_STAMP_KERNEL
+extern "C" int cuddle_debug_stamps(uint64_t *out, uint32_t n_blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_stamps), (size_t)std::min(n_blocks, kStampBlocks) * 64);
 }
 #endif
 
 // Scan + phase-1 selection for the leaf lists in pl.leaves / pl.lcount.
 static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32_t nq, hipStream_t s) {
     const IndexDev &v = ix->dev;
-#ifdef CUDDLE_SCAN_TIMING
-    g_scan_stamps = pl.gdist;
-#endif
     // longest queries first (nq <= kMaxChunk = 4096 fits one sorting block)
     hipLaunchKernelGGL(cand_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, pl.leaves, pl.lstride, pl.lcount, nq,
                        pl.cand_count);

@@ -49,6 +49,21 @@ struct IndexDev {
 // small helpers
 // ---------------------------------------------------------------------------------------------
 
+// Debug builds (-DCUDDLE_STAMP_KERNEL=<id>) record the 100 MHz clock at up to 8 points of every
+// block of ONE kernel (1 Hamming scan, 2 grouped routing distances, 3 register selection,
+// 4 routing finish, 5 register prefilter); cuddle_debug_stamps() reads them back.
+#ifdef CUDDLE_STAMP_KERNEL
+constexpr uint32_t kStampBlocks = 16384;
+__device__ uint64_t g_dbg_stamps[kStampBlocks * 8];
+#define CUDDLE_STAMP(kernel_id, n)                                                                   \
+    do {                                                                                             \
+        if ((kernel_id) == CUDDLE_STAMP_KERNEL && threadIdx.x == 0 && blockIdx.x < kStampBlocks)     \
+            g_dbg_stamps[blockIdx.x * 8 + (n)] = wall_clock64();                                     \
+    } while (0)
+#else
+#define CUDDLE_STAMP(kernel_id, n) do { } while (0)
+#endif
+
 // Order-preserving map f32 -> u32 for "a < b" comparisons as the reference's partial_cmp sees
 // them: -0.0 == +0.0, NaN after everything.
 __device__ __forceinline__ uint32_t f32_key(float d) {
@@ -110,6 +125,39 @@ __device__ __forceinline__ void block_bitonic_sort_u64(uint64_t *s, uint32_t n) 
             }
             __syncthreads();
         }
+    }
+}
+
+// The same sort done by wave 0 alone (the other waves skip it): no block barrier between the
+// steps, which is what a block-wide sort of a few hundred keys spends its time on. The caller
+// puts a __syncthreads() before and after.
+__device__ __forceinline__ void wave0_bitonic_sort_u64(uint64_t *s, uint32_t n) {
+    if (threadIdx.x >= 64) return;
+    for (uint32_t k = 2; k <= n; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (n >> 1); t += 64) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j; // t-th pair of this step
+                const uint64_t a = s[i], b = s[ixj];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    s[i] = b;
+                    s[ixj] = a;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// Sort of n (power of two) keys by the whole block, or by wave 0 alone when n is small.
+__device__ __forceinline__ void block_sort_u64(uint64_t *s, uint32_t n) {
+    if (n <= 512) {
+        wave0_bitonic_sort_u64(s, n);
+        __syncthreads();
+    } else {
+        block_bitonic_sort_u64(s, n);
     }
 }
 
@@ -847,16 +895,6 @@ order_by_work_kernel(const uint32_t *cand_count, uint32_t nq, uint32_t *order) {
 // sel_pos / sel_key: [nq][sel_stride]; gdist: [nq][gdist_stride] spill.
 // One instantiation per code width (PAIRS = 0: any width, generic loop) so that each gets its own
 // register allocation; gdist_v points at DistT elements.
-// Debug builds (-DCUDDLE_SCAN_TIMING) stamp the 100 MHz clock at the phase boundaries of every
-// block into the spill buffer (which such a run must not otherwise use).
-#ifdef CUDDLE_SCAN_TIMING
-#define CUDDLE_STAMP(n)                                                                                      \
-    do {                                                                                                     \
-        if (threadIdx.x == 0) reinterpret_cast<uint64_t *>(gdist_v)[(uint64_t)q * 8 + (n)] = wall_clock64(); \
-    } while (0)
-#else
-#define CUDDLE_STAMP(n) do { } while (0)
-#endif
 #ifndef CUDDLE_SCAN_WAVES
 #define CUDDLE_SCAN_WAVES 1
 #endif
@@ -871,7 +909,7 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const uint32_t D = ix.dim, W = ix.words;
     ScanLds s = scan_lds_carve(smem, D, W, lcap, tcap, PAIRS == 1 && !TAIL);
-    CUDDLE_STAMP(0);
+    CUDDLE_STAMP(1, 0);
     const uint32_t nl = min(lcount[q], lcap);
     for (uint32_t i = tid; i < D + 2; i += blockDim.x) s.hist[i] = 0;
     for (uint32_t i = tid; i < W; i += blockDim.x) s.qw[i] = qcodes[(uint64_t)q * W + i];
@@ -882,7 +920,7 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
         if (tid == 0) sel_count[q] = 0;
         return;
     }
-    CUDDLE_STAMP(1);
+    CUDDLE_STAMP(1, 1);
     DistT *dist = C <= dist_cap ? reinterpret_cast<DistT *>(s.dist)
                                    : reinterpret_cast<DistT *>(gdist_v) + (uint64_t)q * gdist_stride;
     // phase 1
@@ -900,7 +938,7 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
         }
     }
     __syncthreads();
-    CUDDLE_STAMP(2);
+    CUDDLE_STAMP(1, 2);
     // phase 2
     uint32_t T, budget;
     if (C <= rerank_k) {
@@ -931,7 +969,7 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
         T = s.misc[0];
         budget = s.misc[1];
     }
-    CUDDLE_STAMP(3);
+    CUDDLE_STAMP(1, 3);
     // phase 3: the selected scan positions are staged (in the tile tables, which phase 1 no longer
     // needs, or in sel_pos itself when the selection is larger than those), then mapped to
     // leaf-contiguous positions by all threads.
@@ -957,7 +995,7 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
         sp[r] = s.lbeg[sl] + (i - s.lscan[sl]);
         sk[r] = dist[i];
     }
-    CUDDLE_STAMP(4);
+    CUDDLE_STAMP(1, 4);
     if (tid == 0) sel_count[q] = nsel;
 }
 

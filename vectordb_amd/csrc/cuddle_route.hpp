@@ -87,35 +87,111 @@ constexpr int kGroupNQ = 8;           // queries per tile of route_dist_grouped_
 constexpr int kGroupPairs = 64;       // pairs per block of route_dist_grouped_kernel (8 tiles)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// Radix select over keys held in registers (KPT per thread, key t of thread tid is item
+// t * THREADS + tid; items >= n hold 0xFFFFFFFF): returns the want-th smallest key (1-based) and,
+// in `budget`, how many of the keys equal to it belong to the `want` smallest. The leading bits
+// that every key shares (found from the block's min and max) cost nothing; each pass over the rest
+// is one counting sweep with LDS atomics and ONE barrier: each wave then scans the 256 counters itself.
+// hist: 4 * 256 u32 of LDS, zeroed here; wred: 2 * (THREADS / 64) u32. All threads call.
+template <int THREADS, int KPT>
+__device__ __forceinline__ uint32_t reg_radix_select(const uint32_t (&keys)[KPT], uint32_t n, uint32_t want, uint32_t *hist,
+                                                     uint32_t *wred, uint32_t &budget) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int t = 0; t < KPT; ++t) {
+        if ((uint32_t)t * THREADS + tid < n) {
+            kmin = min(kmin, keys[t]);
+            kmax = max(kmax, keys[t]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+    }
+    if (lane == 0) {
+        wred[w] = kmin;
+        wred[THREADS / 64 + w] = kmax;
+    }
+    for (uint32_t i = tid; i < 4 * 256; i += THREADS) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t v = 0; v < THREADS / 64; ++v) {
+        kmin = min(kmin, wred[v]);
+        kmax = max(kmax, wred[THREADS / 64 + v]);
+    }
+    // Bits above the highest bit in which min and max differ are common to every key; the digits
+    // start right below them, so that the first (all-keys) pass spreads over the whole histogram.
+    const uint32_t diff = kmin ^ kmax;
+    if (diff == 0) { // all keys equal
+        budget = want;
+        return kmin;
+    }
+    uint32_t rem = 32 - __clz(diff);                                  // bits still undecided
+    uint32_t prefix = rem == 32 ? 0u : (kmin >> rem) << rem;
+    for (int pass = 0; rem > 0; ++pass) {
+        const uint32_t wbits = min(8u, rem), shift = rem - wbits, dmask = (1u << wbits) - 1;
+        uint32_t *h = hist + 256 * pass;
+#pragma unroll
+        for (int t = 0; t < KPT; ++t) {
+            const bool in = (uint32_t)t * THREADS + tid < n && (rem == 32 || (keys[t] >> rem) == (prefix >> rem));
+            if (in) atomicAdd(&h[(keys[t] >> shift) & dmask], 1u);
+        }
+        __syncthreads();
+        // every wave: prefix-sum the 256 counters, 4 per lane, and find the bucket holding the want-th key
+        const uint32_t h0 = h[4 * lane], h1 = h[4 * lane + 1], h2 = h[4 * lane + 2], h3 = h[4 * lane + 3];
+        const uint32_t s4 = h0 + h1 + h2 + h3;
+        const uint32_t incl = wave_inclusive_sum(s4);
+        const uint64_t hit = __ballot(incl >= want);
+        const uint32_t first = hit ? (uint32_t)__ffsll((unsigned long long)hit) - 1 : 63u;
+        uint32_t cum = incl - s4, b = 4 * lane;
+        if (cum + h0 < want) { cum += h0; ++b;
+            if (cum + h1 < want) { cum += h1; ++b;
+                if (cum + h2 < want) { cum += h2; ++b; } } }
+        prefix |= (uint32_t)__shfl((int)b, first, 64) << shift;
+        want -= (uint32_t)__shfl((int)cum, first, 64);
+        rem = shift;
+    }
+    budget = want;
+    return prefix;
+}
+
 // Split the chosen nodes into leaves and internal nodes (hierarchical.rs:411-413), append the
 // leaves to the query's leaf list (:416) and write the children of the internal nodes, in order,
 // as the next frontier (:419-422; skipped when nf is null: the next level's frontier is then the
 // level's full node list, known without writing it per query). skeys[i] (low 32 bits) = position
-// in `fr` of the i-th chosen node. cnt_leaf / cnt_child: nsel + 1 u32 of LDS each. All threads call.
+// in `fr` of the i-th chosen node. xs: 4 * cap1 u32 of LDS scratch, cap1 > nsel. All threads call.
 __device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t *fr, const uint64_t *skeys,
-                                             uint32_t nsel, uint32_t *cnt_leaf, uint32_t *cnt_child, uint32_t *nf,
+                                             uint32_t nsel, uint32_t *xs, uint32_t cap1, uint32_t *nf,
                                              uint32_t fstride, uint32_t *next_fcount_q, uint32_t *lv, uint32_t lstride,
                                              uint32_t *lcount_q, const PairOut &po = PairOut(), uint32_t q = 0) {
+    uint32_t *cnt_leaf = xs, *cnt_child = xs + cap1, *sel_node = xs + 2 * cap1, *sel_cb = xs + 3 * cap1;
     const uint32_t tid = threadIdx.x;
+    const uint32_t lbase = *lcount_q; // read by every thread three barriers before thread 0 replaces it
     for (uint32_t i = tid; i < nsel; i += blockDim.x) {
-        uint32_t node = fr[(uint32_t)skeys[i]];
-        uint32_t cc = ix.child_off[node + 1] - ix.child_off[node];
+        const uint32_t node = fr[(uint32_t)skeys[i]];
+        const uint32_t cb = ix.child_off[node], cc = ix.child_off[node + 1] - cb;
         cnt_leaf[i] = cc == 0 ? 1u : 0u;
         cnt_child[i] = cc;
+        sel_node[i] = node;
+        sel_cb[i] = cb;
     }
     __syncthreads();
     wave0_exclusive_scan_lds(cnt_leaf, nsel);
     __syncthreads();
     wave0_exclusive_scan_lds(cnt_child, nsel);
     __syncthreads();
-    const uint32_t lbase = *lcount_q;
+    if (tid == 0) {
+        *lcount_q = min(lbase + cnt_leaf[nsel], lstride);
+        if (nf) *next_fcount_q = min(cnt_child[nsel], fstride);
+    }
     if (po.info) {
         const uint32_t nchild = cnt_child[nsel];
         const bool grouped = nf && nchild > po.min_n && nchild <= fstride;
         for (uint32_t i = tid; i < po.pstride; i += blockDim.x) {
             uint32_t info = 0xFFFFFFFFu, par = 0;
             if (grouped && i < nsel && cnt_child[i + 1] > cnt_child[i]) {
-                par = ix.level_pos[fr[(uint32_t)skeys[i]]];
+                par = ix.level_pos[sel_node[i]];
                 info = (q << kPairOffBits) | cnt_child[i];
                 atomicAdd(&po.cnt[par], 1u);
             }
@@ -127,23 +203,17 @@ __device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t 
     // one wave per chosen node: leaves are appended, children copied with coalesced stores
     const uint32_t nw = blockDim.x >> 6, w = tid >> 6, lane = tid & 63;
     for (uint32_t i = w; i < nsel; i += nw) {
-        uint32_t node = fr[(uint32_t)skeys[i]];
-        uint32_t cb = ix.child_off[node], ce = ix.child_off[node + 1];
-        if (cb == ce) {
+        const uint32_t cb = sel_cb[i], cc = cnt_child[i + 1] - cnt_child[i];
+        if (cc == 0) {
             if (lane == 0) {
-                uint32_t slot = lbase + cnt_leaf[i];
-                if (slot < lstride) lv[slot] = node;
+                const uint32_t slot = lbase + cnt_leaf[i];
+                if (slot < lstride) lv[slot] = sel_node[i];
             }
         } else if (nf) {
-            uint32_t ob = cnt_child[i];
-            for (uint32_t c = lane; c < ce - cb; c += 64)
+            const uint32_t ob = cnt_child[i];
+            for (uint32_t c = lane; c < cc; c += 64)
                 if (ob + c < fstride) nf[ob + c] = ix.children[cb + c];
         }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        *lcount_q = min(lbase + cnt_leaf[nsel], lstride);
-        if (nf) *next_fcount_q = min(cnt_child[nsel], fstride);
     }
 }
 
@@ -211,8 +281,12 @@ route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, u
     }
 }
 
+inline size_t route_select_reg_lds_bytes(uint32_t scap) { // route_select_reg_kernel: four radix histograms
+    return (size_t)scap * 8 + 4 * 256 * 4 + 32 * 4 + 8 * 4 + 4 * ((size_t)scap + 1) * 4 + 16;
+}
+
 inline size_t route_select_lds_bytes(uint32_t scap) {
-    return (size_t)scap * 8 + 256 * 4 + 32 * 4 + 8 * 4 + 2 * ((size_t)scap + 1) * 4 + 16;
+    return (size_t)scap * 8 + 256 * 4 + 32 * 4 + 8 * 4 + 4 * ((size_t)scap + 1) * 4 + 16;
 }
 
 // Per query: choose the nodes to descend into (hierarchical.rs:393-408) and expand them.
@@ -232,8 +306,7 @@ route_select_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, con
     uint32_t *hist = reinterpret_cast<uint32_t *>(skeys + scap);         // [256]
     uint32_t *wtmp = hist + 256;                                         // [2 * waves]
     uint32_t *misc = wtmp + 32;                                          // [8]
-    uint32_t *cnt_leaf = misc + 8;                                       // [scap + 1]
-    uint32_t *cnt_child = cnt_leaf + scap + 1;                           // [scap + 1]
+    uint32_t *xs = misc + 8;                                             // [4 * (scap + 1)]
     const uint32_t q = blockIdx.x;
     if (only_flag && !only_flag[q]) return;
     const uint32_t n = shared_fr ? shared_n : fcount[q];
@@ -272,22 +345,21 @@ route_select_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, con
             for (uint32_t i = nsel + tid; i < npad; i += blockDim.x) skeys[i] = ~0ull;
             __syncthreads();
         }
-        block_bitonic_sort_u64(skeys, npad);
+        block_sort_u64(skeys, npad);
     }
-    route_expand(ix, fr, skeys, nsel, cnt_leaf, cnt_child,
+    route_expand(ix, fr, skeys, nsel, xs, scap + 1,
                  next_frontier ? next_frontier + (uint64_t)q * fstride : nullptr, fstride, next_fcount + q,
                  leaves + (uint64_t)q * lstride, lstride, lcount + q, po, q);
 }
 
-constexpr int kSelKpt = 32; // register-resident selection: n <= 32 * THREADS
 
-// route_select_kernel for levels whose frontiers hold at most kSelKpt * THREADS nodes: the keys
+// route_select_kernel for levels whose frontiers hold at most KPT * THREADS nodes: the keys
 // are read once and kept in registers, radix passes whose digit is the same for every key are
 // skipped (no counting, no same-address atomics), and the winners are collected in any order
 // before the sort by (distance, frontier position) — unless the keys equal to the threshold
 // outnumber the places left for them, in which case the earliest positions must win and the
 // ordered compaction decides. Same arguments, same result; dynamic LDS = route_select_lds_bytes(scap).
-template <int THREADS>
+template <int THREADS, int KPT>
 __global__ void __launch_bounds__(THREADS)
 route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, const uint32_t *fcount,
                         const uint32_t *shared_fr, uint32_t shared_n, const float *fdist, uint32_t probes,
@@ -295,15 +367,14 @@ route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride,
                         uint32_t *leaves, uint32_t lstride, uint32_t *lcount, const uint32_t *only_flag, PairOut po) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);                 // [scap]
-    uint32_t *hist = reinterpret_cast<uint32_t *>(skeys + scap);         // [256]
-    uint32_t *wtmp = hist + 256;                                         // [2 * waves]
+    uint32_t *hist = reinterpret_cast<uint32_t *>(skeys + scap);         // [4 * 256]
+    uint32_t *wtmp = hist + 4 * 256;                                     // [2 * waves]
     uint32_t *misc = wtmp + 32;                                          // [8]
-    uint32_t *cnt_leaf = misc + 8;                                       // [scap + 1]
-    uint32_t *cnt_child = cnt_leaf + scap + 1;                           // [scap + 1]
+    uint32_t *xs = misc + 8;                                             // [4 * (scap + 1)]
     const uint32_t q = blockIdx.x;
     if (only_flag && !only_flag[q]) return;
     const uint32_t n = shared_fr ? shared_n : fcount[q];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t tid = threadIdx.x;
     if (n == 0) {
         if (tid == 0 && next_frontier) next_fcount[q] = 0;
         if (po.info) {
@@ -314,6 +385,7 @@ route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride,
     }
     const uint32_t *fr = shared_fr ? shared_fr : frontier + (uint64_t)q * fstride;
     const float *fd = fdist + (uint64_t)q * fstride;
+    CUDDLE_STAMP(3, 0);
     uint32_t nsel;
     const bool keep_all = !stats_variant && n <= probes;
     if (keep_all) {
@@ -329,76 +401,26 @@ route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride,
                 skeys[i] = i < n ? (((uint64_t)f32_key(fd[i]) << 32) | i) : ~0ull;
             __syncthreads();
         } else {
-            uint32_t keys[kSelKpt];
-            uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+            uint32_t keys[KPT];
 #pragma unroll
-            for (int t = 0; t < kSelKpt; ++t) {
+            for (int t = 0; t < KPT; ++t) {
                 const uint32_t i = t * THREADS + tid;
                 keys[t] = i < n ? f32_key(fd[i]) : 0xFFFFFFFFu;
-                if (i < n) {
-                    kmin = min(kmin, keys[t]);
-                    kmax = max(kmax, keys[t]);
-                }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
-                kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
-            }
-            if (lane == 0) {
-                wtmp[w] = kmin;
-                wtmp[THREADS / 64 + w] = kmax;
-            }
-            if (tid < 2) misc[2 + tid] = 0; // winner counter, tie counter
-            __syncthreads();
-            for (uint32_t v = 0; v < THREADS / 64; ++v) {
-                kmin = min(kmin, wtmp[v]);
-                kmax = max(kmax, wtmp[THREADS / 64 + v]);
-            }
-            uint32_t prefix = 0, want = nsel;
-            for (int shift = 24; shift >= 0; shift -= 8) {
-                if ((kmin >> shift) == (kmax >> shift)) { // every key has this digit (and all higher bits) in common
-                    prefix |= ((kmin >> shift) & 255u) << shift;
-                    continue;
-                }
-                for (uint32_t i = tid; i < 256; i += THREADS) hist[i] = 0;
-                __syncthreads();
-                const uint32_t himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
-#pragma unroll
-                for (int t = 0; t < kSelKpt; ++t) {
-                    const uint32_t i = t * THREADS + tid;
-                    if (i < n && (keys[t] & himask) == prefix) atomicAdd(&hist[(keys[t] >> shift) & 255u], 1u);
-                }
-                __syncthreads();
-                if (tid < 64) {
-                    const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-                    const uint32_t s4 = h0 + h1 + h2 + h3;
-                    const uint32_t incl = wave_inclusive_sum(s4);
-                    const uint64_t hit = __ballot(incl >= want);
-                    const uint32_t first = hit ? (uint32_t)__ffsll((unsigned long long)hit) - 1 : 63u;
-                    if (tid == first) {
-                        uint32_t cum = incl - s4, b = 4 * tid;
-                        if (cum + h0 < want) { cum += h0; ++b;
-                            if (cum + h1 < want) { cum += h1; ++b;
-                                if (cum + h2 < want) { cum += h2; ++b; } } }
-                        misc[0] = prefix | (b << shift);
-                        misc[1] = want - cum;
-                    }
-                }
-                __syncthreads();
-                prefix = misc[0];
-                want = misc[1];
-                __syncthreads();
-            }
+            if (tid < 2) misc[2 + tid] = 0; // winner counter, tie counter (visible after the barriers inside the select)
+            CUDDLE_STAMP(3, 1);
+            uint32_t want;
+            const uint32_t prefix = reg_radix_select<THREADS, KPT>(keys, n, nsel, hist, wtmp, want);
+            CUDDLE_STAMP(3, 2);
             const uint32_t T = prefix, budget = want;
             uint32_t my_ties = 0;
 #pragma unroll
-            for (int t = 0; t < kSelKpt; ++t) my_ties += (t * THREADS + tid < n && keys[t] == T) ? 1u : 0u;
+            for (int t = 0; t < KPT; ++t) my_ties += (t * THREADS + tid < n && keys[t] == T) ? 1u : 0u;
             if (my_ties) atomicAdd(&misc[3], my_ties);
             __syncthreads();
             if (misc[3] == budget) { // every key equal to the threshold is selected: order is the sort's business
 #pragma unroll
-                for (int t = 0; t < kSelKpt; ++t) {
+                for (int t = 0; t < KPT; ++t) {
                     const uint32_t i = t * THREADS + tid;
                     if (i < n && keys[t] <= T) skeys[atomicAdd(&misc[2], 1u)] = ((uint64_t)keys[t] << 32) | i;
                 }
@@ -411,11 +433,14 @@ route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride,
             for (uint32_t i = nsel + tid; i < npad; i += blockDim.x) skeys[i] = ~0ull;
             __syncthreads();
         }
-        block_bitonic_sort_u64(skeys, npad);
+        CUDDLE_STAMP(3, 3);
+        block_sort_u64(skeys, npad);
     }
-    route_expand(ix, fr, skeys, nsel, cnt_leaf, cnt_child,
+    CUDDLE_STAMP(3, 4);
+    route_expand(ix, fr, skeys, nsel, xs, scap + 1,
                  next_frontier ? next_frontier + (uint64_t)q * fstride : nullptr, fstride, next_fcount + q,
                  leaves + (uint64_t)q * lstride, lstride, lcount + q, po, q);
+    CUDDLE_STAMP(3, 5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -487,18 +512,8 @@ __global__ void pair_fill_kernel(const uint32_t *info, const uint32_t *parent, u
 //     barrier per tile), four queries at a time to bound the accumulator registers.
 //   NBLK == 0: any dim. The slice is re-read in segments of 8 chunks for every tile.
 // METRIC is the index metric. dynamic LDS = 2 * kGroupNQ * pad4(dim) floats.
-#ifdef CUDDLE_GROUP_TIMING // debug builds: 100 MHz clock stamps per block (start, rows loaded, first tile staged, end)
-__device__ uint64_t g_group_stamps[16384 * 4];
-#define CUDDLE_GSTAMP(n)                                                                          \
-    do {                                                                                          \
-        if (threadIdx.x == 0 && blockIdx.x < 16384) g_group_stamps[blockIdx.x * 4 + (n)] = wall_clock64(); \
-    } while (0)
-#else
-#define CUDDLE_GSTAMP(n) do { } while (0)
-#endif
-
 template <int NBLK, uint32_t METRIC>
-__global__ void __launch_bounds__(256, NBLK > 8 ? 2 : 4) // waves per SIMD the register allocation must allow
+__global__ void __launch_bounds__(256, (NBLK > 8 ? 2 : 4) - (METRIC == kMetricCosine ? 1 : 0)) // waves per SIMD the registers must allow
 route_dist_grouped_kernel(IndexDev ix, const float *queries, const uint32_t *level_nodes, uint32_t n_parents,
                           const uint32_t *ioff, const uint4 *items, const uint32_t *sorted, float *fdist,
                           uint32_t fstride) {
@@ -510,7 +525,7 @@ route_dist_grouped_kernel(IndexDev ix, const float *queries, const uint32_t *lev
     const uint32_t n_items = ioff[n_parents];
     const uint4 rec = items[min(item, max(n_items, 1u) - 1)];
     if (item >= n_items) return;
-    CUDDLE_GSTAMP(0);
+    CUDDLE_STAMP(2, 0);
     const uint32_t p = rec.x, pb = rec.y, np = rec.z;
     const uint32_t D = NBLK > 0 ? 16u * NBLK : ix.dim, Dp = (D + 3) & ~3u, tid = threadIdx.x;
     if (tid < kGroupPairs) pk[tid] = sorted[pb + min(tid, np - 1)]; // unused slots repeat the last pair
@@ -531,10 +546,7 @@ route_dist_grouped_kernel(IndexDev ix, const float *queries, const uint32_t *lev
             for (int t = 0; t < NBLK; ++t) y[t] = *reinterpret_cast<const float4 *>(row + 4 * sub + 16 * t);
         }
         if (METRIC == kMetricCosine) nb = sqrtf(neon16_group4<false>(row, row, D, sub, vec));
-#ifdef CUDDLE_GROUP_TIMING
-        if (NBLK > 0 && y[0].x == 12345.678f) nb = 1.f; // wait for the rows before the stamp
-#endif
-        CUDDLE_GSTAMP(1);
+        CUDDLE_STAMP(2, 1);
         __syncthreads(); // pk ready (first pass) / last tile of the previous pass consumed
         float4 pf[PF];
         // queries of tile t0 -> registers: float4 number f of the tile = tid + 256 k
@@ -559,7 +571,7 @@ route_dist_grouped_kernel(IndexDev ix, const float *queries, const uint32_t *lev
             stash(qbuf);
             __syncthreads();
         }
-        CUDDLE_GSTAMP(2);
+        CUDDLE_STAMP(2, 2);
         for (uint32_t t0 = 0, it = 0; t0 < np; t0 += kGroupNQ, ++it) {
             float *qs = qbuf + (NBLK > 0 ? (it & 1) * kGroupNQ * Dp : 0);
             if (NBLK > 0) {
@@ -665,7 +677,7 @@ route_dist_grouped_kernel(IndexDev ix, const float *queries, const uint32_t *lev
             }
         }
     }
-    CUDDLE_GSTAMP(3);
+    CUDDLE_STAMP(2, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -878,72 +890,20 @@ template <int THREADS>
 __global__ void __launch_bounds__(THREADS)
 route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_t kc, uint32_t *cand_pos,
                            uint32_t cstride, float *cand_max) {
-    __shared__ uint32_t hist[256];
+    __shared__ uint32_t hist[4 * 256];
     __shared__ uint32_t misc[4];
     __shared__ uint32_t wred[2 * (THREADS / 64)];
-    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const float *fd = fdist + (uint64_t)q * fstride;
     uint32_t keys[kPrefKpt];
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
     for (int t = 0; t < kPrefKpt; ++t) {
         const uint32_t i = t * THREADS + tid;
         keys[t] = i < n ? f32_key(fd[i]) : 0xFFFFFFFFu;
-        if (i < n) {
-            kmin = min(kmin, keys[t]);
-            kmax = max(kmax, keys[t]);
-        }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
-        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
-    }
-    if (lane == 0) {
-        wred[w] = kmin;
-        wred[THREADS / 64 + w] = kmax;
-    }
-    if (tid < 2) misc[2 + tid] = 0; // winner counters
-    __syncthreads();
-    for (uint32_t v = 0; v < THREADS / 64; ++v) {
-        kmin = min(kmin, wred[v]);
-        kmax = max(kmax, wred[THREADS / 64 + v]);
-    }
-    uint32_t prefix = 0, want = kc;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        if ((kmin >> shift) == (kmax >> shift)) { // every key has this digit (and all higher bits) in common
-            prefix |= ((kmin >> shift) & 255u) << shift;
-            continue;
-        }
-        for (uint32_t i = tid; i < 256; i += THREADS) hist[i] = 0;
-        __syncthreads();
-        const uint32_t himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
-#pragma unroll
-        for (int t = 0; t < kPrefKpt; ++t) {
-            const uint32_t i = t * THREADS + tid;
-            if (i < n && (keys[t] & himask) == prefix) atomicAdd(&hist[(keys[t] >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-            const uint32_t s4 = h0 + h1 + h2 + h3;
-            const uint32_t incl = wave_inclusive_sum(s4);
-            const uint64_t hit = __ballot(incl >= want);
-            const uint32_t first = hit ? (uint32_t)__ffsll((unsigned long long)hit) - 1 : 63u;
-            if (tid == first) {
-                uint32_t cum = incl - s4, b = 4 * tid;
-                if (cum + h0 < want) { cum += h0; ++b;
-                    if (cum + h1 < want) { cum += h1; ++b;
-                        if (cum + h2 < want) { cum += h2; ++b; } } }
-                misc[0] = prefix | (b << shift);
-                misc[1] = want - cum;
-            }
-        }
-        __syncthreads();
-        prefix = misc[0];
-        want = misc[1];
-        __syncthreads();
-    }
+    if (tid < 2) misc[2 + tid] = 0; // winner counters (visible after the barriers inside the select)
+    uint32_t want;
+    const uint32_t prefix = reg_radix_select<THREADS, kPrefKpt>(keys, n, kc, hist, wred, want);
     const uint32_t T = prefix, budget = want, n_lt = kc - budget;
     uint32_t *cp = cand_pos + (uint64_t)q * cstride;
 #pragma unroll
@@ -982,7 +942,7 @@ route_refine_kernel(IndexDev ix, const float *queries, const uint32_t *level_nod
 }
 
 inline size_t route_finish_lds_bytes(uint32_t kpad, uint32_t probes) {
-    return (size_t)kpad * 8 + 2 * ((size_t)probes + 1) * 4 + 16;
+    return (size_t)kpad * 8 + 4 * ((size_t)probes + 1) * 4 + 16;
 }
 
 // Per query: sort the refined candidates by (exact distance, level position); the first `probes`
@@ -998,14 +958,13 @@ route_finish_kernel(IndexDev ix, const uint32_t *level_nodes, uint32_t n, const 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t kpad = next_pow2(kc);
     uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);
-    uint32_t *cnt_leaf = reinterpret_cast<uint32_t *>(skeys + kpad);
-    uint32_t *cnt_child = cnt_leaf + probes + 1;
+    uint32_t *xs = reinterpret_cast<uint32_t *>(skeys + kpad);
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     for (uint32_t i = tid; i < kpad; i += blockDim.x)
         skeys[i] = i < kc ? (((uint64_t)f32_key(cand_dist[(uint64_t)q * cstride + i]) << 32) | cand_pos[(uint64_t)q * cstride + i])
                           : ~0ull;
     __syncthreads();
-    block_bitonic_sort_u64(skeys, kpad);
+    block_sort_u64(skeys, kpad);
     const float tau = f32_from_key((uint32_t)(skeys[probes - 1] >> 32));
     const float e = route_error_bound(ix.metric, ix.dim, qsq[q], max_csq);
     const bool ok = kc >= n || (cand_max[q] - e > tau);
@@ -1017,7 +976,7 @@ route_finish_kernel(IndexDev ix, const uint32_t *level_nodes, uint32_t n, const 
         return;
     }
     if (tid == 0) flag[q] = 0;
-    route_expand(ix, level_nodes, skeys, probes, cnt_leaf, cnt_child, next_frontier + (uint64_t)q * fstride, fstride,
+    route_expand(ix, level_nodes, skeys, probes, xs, probes + 1, next_frontier + (uint64_t)q * fstride, fstride,
                  next_fcount + q, leaves + (uint64_t)q * lstride, lstride, lcount + q, po, q);
 }
 
