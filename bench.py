@@ -109,11 +109,15 @@ def cpu_baseline(fi, queries_np, k, probes, rf, budget_s=12.0):
     dt = time.perf_counter() - t0
     per_q = dt / n
     sample = int(min(queries_np.shape[0], max(n, budget_s / max(per_q, 1e-9))))
-    t0 = time.perf_counter()
-    rc, ids, _, _ = oi.search_batch(queries_np[:sample], k, probes, rf, 0, threads)
-    dt = time.perf_counter() - t0
-    return dict(value=sample / dt, unit="queries/s", cores=threads, kind="port",
-                sample=f"{sample} of the {queries_np.shape[0]} benchmark queries, same index and parameters, "
+    # at least ~1 s of wall time (about 16 core-seconds): repeat the sample if it is the whole query set
+    passes, dt = 0, 0.0
+    while passes == 0 or (dt < 1.0 and passes < 64):
+        t0 = time.perf_counter()
+        rc, ids, _, _ = oi.search_batch(queries_np[:sample], k, probes, rf, 0, threads)
+        dt += time.perf_counter() - t0
+        passes += 1
+    return dict(value=sample * passes / dt, unit="queries/s", cores=threads, kind="port",
+                sample=f"{sample} of the {queries_np.shape[0]} benchmark queries x {passes} passes, same index and parameters, "
                        f"{dt:.1f} s wall, oracle/cuddle_oracle.c with OpenMP (one query per thread)"), ids, sample
 
 
@@ -285,8 +289,11 @@ def main():
                     algorithmic_bytes_per_launch=scan_bytes, avg_launch_ms=scan_ms,
                     stage_ms_per_step={n: stage[n] / n_timed for n in _ffi.STAGE_NAMES},
                     rerank_GBps=(rerank_bytes / (stage["rerank"] / n_timed * 1e-3) / 1e9) if stage["rerank"] > 0 else 0.0,
-                    note="the code array of a 1M-vector index (<= 128 MB) fits the 256 MiB Infinity Cache, so re-reads "
-                         "across queries may be served on-die; the rate is algorithmic bytes per second")
+                    code_array_bytes=cfg["n"] * code_bytes,
+                    note=("the whole code array fits the 256 MiB Infinity Cache, so re-reads across queries may be served "
+                          "on-die; " if cfg["n"] * code_bytes <= (256 << 20) else
+                          "the code array is larger than the 256 MiB Infinity Cache; ") +
+                         "achieved = algorithmic bytes per second, traffic = HBM bytes per launch from the PMC counters")
 
     cpu = None
     if not args.no_cpu_baseline and fi is not None:
