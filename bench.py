@@ -36,7 +36,7 @@ from vectordb_amd.builder import build_index  # noqa: E402
 from vectordb_amd.datasets import brute_force_topk, recall_at_k, synthetic_mixture  # noqa: E402
 from vectordb_amd.flat_index import FlatIndex  # noqa: E402
 from vectordb_amd.index import DeviceIndex  # noqa: E402
-from vectordb_amd.sharded import ShardedSearcher  # noqa: E402
+from vectordb_amd.sharded import ExactShardedSearcher, ShardedSearcher  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 
@@ -70,6 +70,12 @@ CONFIGS = {
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def trace(msg):
+    """Progress of every rank (CUDDLE_BENCH_TRACE=1): where a multi-rank run stops."""
+    if os.environ.get("CUDDLE_BENCH_TRACE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')} {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def broadcast_flat(fi, src_rank, device):
@@ -133,6 +139,9 @@ def main():
     ap.add_argument("--threshold", default="mean", choices=["mean", "reference"],
                     help="binary threshold: exact mean, or the reference's saturating f32 running sum")
     ap.add_argument("--probes", type=int, default=0)
+    ap.add_argument("--sharded", default="exact", choices=["exact", "simple"],
+                    help="N > 1: 'exact' reproduces the single-index result bit for bit (two small all-reduces + one "
+                         "all-gather per batch); 'simple' lets every rank rerank its own top candidates (one all-gather)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,10 +149,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    # one GPU per rank; CUDDLE_BENCH_BACKEND=gloo lets several ranks share a GPU to rehearse the N > 1 flow on a 1-GPU box
+    backend = os.environ.get("CUDDLE_BENCH_BACKEND", "nccl")
+    local_rank = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     cfg = dict(CONFIGS[args.config])
     if args.n:
@@ -204,10 +219,21 @@ def main():
     def local_search(q, kk, pp, rr):
         return dev_index.search_batch_device(q, kk, pp, rr, flags, out_ids, out_dist, out_cnt)
 
-    searcher = ShardedSearcher(local_search)
+    class _ShardEngine:  # this rank's shard behind the three-step interface, stage timing on
+        def shard_scan(self, q, kk, pp, rr):
+            return dev_index.shard_scan(q, kk, pp, rr, flags)
+
+        shard_ties = staticmethod(dev_index.shard_ties)
+        shard_finish = staticmethod(dev_index.shard_finish)
+
+    exact = world > 1 and args.sharded == "exact"
+    searcher = ExactShardedSearcher(_ShardEngine()) if exact else ShardedSearcher(local_search)
 
     def step():
-        return searcher.search_batch(queries, k, probes, rf_box[0])
+        out = searcher.search_batch(queries, k, probes, rf_box[0])
+        if world > 1 and backend != "nccl":
+            torch.cuda.synchronize()  # rehearsal backends stage CUDA tensors through the host on their own streams
+        return out
 
     # ---- operating point: cheapest sweep point with recall@10 >= 0.95 ------------------------
     sweep = []
@@ -229,15 +255,18 @@ def main():
     if chosen is None:
         chosen = (args.rerank or cfg["rerank_sweep"][-1])
     rf_box[0] = chosen
+    trace(f"operating point rf={chosen}")
     dev_index.stage_times()  # drop the sweep's timings
 
     # ---- timed region ---------------------------------------------------------------------------
     for _ in range(args.warmup):
         step()
     dev_index.stage_times()
+    trace("warm-up done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    trace("timed region starts")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -245,12 +274,14 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    trace("timed region done")
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     stage = dev_index.stage_times()
     stats = dev_index.last_stats()
+    trace("stage times read")
 
     # per-batch latency distribution (separate loop: one sync per batch)
     lat = []
@@ -263,12 +294,12 @@ def main():
     lat.sort()
     dev_index.stage_times()
 
+    ids, _, _ = step()  # every rank: the search is collective
+    torch.cuda.synchronize()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    ids, _, _ = step()
-    torch.cuda.synchronize()
     recall = recall_at_k(ids.cpu().numpy()[:len(gt)], gt, k)
 
     # ---- roofline of the dominant kernel (the Hamming scan + select) -----------------------------
@@ -299,7 +330,7 @@ def main():
     if not args.no_cpu_baseline and fi is not None:
         log("CPU baseline (oracle port, OpenMP)")
         cpu, cpu_ids, sample = cpu_baseline(fi, queries.cpu().numpy(), k, probes, chosen)
-        same = bool(np.array_equal(cpu_ids[:sample].astype(np.int64), ids.cpu().numpy()[:sample])) if world == 1 else None
+        same = bool(np.array_equal(cpu_ids[:sample].astype(np.int64), ids.cpu().numpy()[:sample])) if (world == 1 or exact) else None
         cpu["gpu_ids_identical_on_sample"] = same
 
     total_q = nq * args.steps
@@ -318,7 +349,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": cfg["label"] + f", L2, k={k}, {nq}-query batch, probes_per_level={probes}, "
                                f"rerank_factor={chosen}" + (f", branching {cfg['branching']} / leaf {cfg['leaf']}" if "branching" in cfg else ""),
-                   "name": args.config, "binary_threshold": args.threshold, "parallelism": f"leaf-sharded x{world}" if world > 1 else "single GPU"},
+                   "name": args.config, "binary_threshold": args.threshold,
+                   "parallelism": (f"leaf-sharded x{world}, {args.sharded} selection" if world > 1 else "single GPU")},
         "recall_at_10": recall,
         "recall_sweep": sweep,
         "p50_batch_ms": lat[len(lat) // 2],

@@ -236,6 +236,38 @@ uint32_t cuddle_index_max_children(const cuddle_index *idx);
 uint32_t cuddle_index_max_leaf_size(const cuddle_index *idx);
 uint64_t cuddle_index_device_bytes(const cuddle_index *idx); /* index arrays + workspace */
 
+/* ---- leaf-sharded exact search ------------------------------------------------------------
+ * No counterpart in the reference, which is a single process (sharding is prose only,
+ * docs/goals/SCALING_GOALS.md:139-147). One index is split by leaves over several handles
+ * (one per GPU; the tree is replicated, a leaf's vectors live on exactly one shard). The three
+ * calls below are cuddle_search_batch_device cut at the two points where the shards must agree,
+ * so that the union of their selections is exactly select_top_candidates
+ * (src/index/hierarchical.rs:645-655) of the whole index:
+ *   cuddle_shard_scan   : query codes, routing, scan of the shard's leaves. d_hist[q][dim+1] gets
+ *                         the shard's Hamming histogram. -> the caller sums d_hist over the shards
+ *                         (all-reduce).
+ *   cuddle_shard_ties   : threshold and tie budget from the summed histogram; d_tie_count
+ *                         [q][*leaf_stride] gets the shard's candidates at the threshold distance
+ *                         per slot of the query's leaf list. -> summed over the shards likewise.
+ *   cuddle_shard_finish : the shard's members of the global selection, rerank, local top-k.
+ *                         d_out_order[q][k] = each result's place in the global phase-1 order
+ *                         (Hamming << 48 | leaf slot << 24 | position in the leaf).
+ * The shards' lists are then merged by (distance, order): cuddle_merge_topk_ordered, or the same
+ * rule on the all-gathered device buffers (vectordb_amd/sharded.py).
+ * All pointers are device pointers; work is enqueued on `stream`; 1..4096 queries per batch;
+ * binary codes only. The handle keeps the batch's state between the calls: no other call on it
+ * in between. */
+cuddle_status cuddle_shard_scan(cuddle_index *idx, const float *d_queries, uint32_t n_queries,
+                                uint32_t dim, uint32_t k, uint32_t probes_per_level,
+                                uint32_t rerank_factor, uint32_t flags, uint32_t *d_hist,
+                                uint32_t *leaf_stride, void *stream);
+cuddle_status cuddle_shard_ties(cuddle_index *idx, const uint32_t *d_global_hist,
+                                uint32_t *d_tie_count, void *stream);
+cuddle_status cuddle_shard_finish(cuddle_index *idx, const float *d_queries,
+                                  const uint32_t *d_global_ties, uint64_t *d_out_ids,
+                                  float *d_out_dist, uint64_t *d_out_order, uint32_t *d_out_count,
+                                  void *stream);
+
 /* ---- multi-GPU merge -------------------------------------------------------------------- */
 /* Merge `n_lists` per-shard result lists (each [n_queries][k], ascending, padded with
  * id = UINT64_MAX / +inf) into the global top-k per query, ties by (distance, list index,
@@ -245,6 +277,13 @@ uint64_t cuddle_index_device_bytes(const cuddle_index *idx); /* index arrays + w
 cuddle_status cuddle_merge_topk(const uint64_t *lists_ids, const float *lists_dist,
                                 uint32_t n_lists, uint32_t n_queries, uint32_t k,
                                 uint64_t *out_ids, float *out_dist, uint32_t *out_count);
+
+/* The same for the lists of cuddle_shard_finish: ties by (distance, order), which is the
+ * finalize_results order (hierarchical.rs:678-691) of the unsharded index. */
+cuddle_status cuddle_merge_topk_ordered(const uint64_t *lists_ids, const float *lists_dist,
+                                        const uint64_t *lists_order, uint32_t n_lists,
+                                        uint32_t n_queries, uint32_t k, uint64_t *out_ids,
+                                        float *out_dist, uint32_t *out_count);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,64 @@
+"""GPU: the exact leaf-sharded protocol (cuddle_shard_scan / _ties / _finish + ordered merge) must
+reproduce the unsharded search bit for bit, whatever the number of shards — here the shards are
+separate handles on the one GPU and the two all-reduces are in-process sums."""
+import numpy as np
+import pytest
+import torch
+
+from vectordb_amd.index import DeviceIndex
+from vectordb_amd.sharded import ExactShardedSearcher, exact_search_in_process
+
+from helpers import clustered, queries_like, small_index
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _check(fi, gpu, q, cases, worlds=(2, 3)):
+    full = DeviceIndex(fi, gpu)
+    dq = torch.from_numpy(q).cuda(gpu)
+    for world in worlds:
+        shards = [DeviceIndex(fi.shard(r, world), gpu) for r in range(world)]
+        for (k, probes, rf) in cases:
+            ids0, d0, c0 = full.search_batch_device(dq, k, probes, rf)
+            ids1, d1, c1 = exact_search_in_process(shards, dq, k, probes, rf)
+            torch.cuda.synchronize()
+            assert torch.equal(c0.cpu(), c1.cpu()), (world, k, probes, rf)
+            assert torch.equal(ids0.cpu(), ids1.cpu()), (world, k, probes, rf)
+            assert np.array_equal(_bits(d0.cpu().numpy()), _bits(d1.cpu().numpy())), (world, k, probes, rf)
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+def test_sharded_equals_unsharded(gpu, metric):
+    x, fi = small_index(n=6000, d=48, n_clusters=40, branching=8, leaf=40, metric=metric)
+    q = queries_like(x, 48, 21)
+    _check(fi, gpu, q, [(10, 4, 3), (10, 6, 10), (1, 2, 1), (20, 8, 1000), (100, 8, 2)])
+
+
+def test_sharded_tie_heavy_and_wide_codes(gpu):
+    # few distinct Hamming values -> the tie budget decides most of the selection
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 2, (3000, 16)).astype(np.float32)
+    from vectordb_amd.builder import build_index
+    fi = build_index(x, 6, 50, "l2", 5, seed=2)
+    q = rng.integers(0, 2, (32, 16)).astype(np.float32)
+    _check(fi, gpu, q, [(10, 3, 2), (5, 6, 7), (10, 6, 40)])
+    # dim >= 255: u16 distances
+    x = clustered(4000, 320, 30, 3, sigma=0.3)
+    fi = build_index(x, 8, 40, "l2", 5, seed=3)
+    _check(fi, gpu, queries_like(x, 24, 4, noise=0.1), [(10, 4, 3), (10, 8, 25)], worlds=(2,))
+
+
+def test_world_of_one_is_the_plain_search(gpu):
+    x, fi = small_index(n=5000, d=32)
+    dev = DeviceIndex(fi, gpu)
+    dq = torch.from_numpy(queries_like(x, 40, 2)).cuda(gpu)
+    ids0, d0, c0 = dev.search_batch_device(dq, 10, 5, 4)
+    ids0, d0, c0 = ids0.clone(), d0.clone(), c0.clone()
+    ids1, d1, c1 = ExactShardedSearcher(dev).search_batch(dq, 10, 5, 4)
+    torch.cuda.synchronize()
+    assert torch.equal(ids0, ids1) and torch.equal(c0, c1)
+    assert np.array_equal(_bits(d0.cpu().numpy()), _bits(d1.cpu().numpy()))

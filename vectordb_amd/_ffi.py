@@ -120,6 +120,10 @@ SIGNATURES = {
     "cuddle_index_max_leaf_size": (_u32, [_vp]),
     "cuddle_index_device_bytes": (_u64, [_vp]),
     "cuddle_merge_topk": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "cuddle_shard_scan": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, C.POINTER(_u32), _vp]),
+    "cuddle_shard_ties": (_int, [_vp, _vp, _vp, _vp]),
+    "cuddle_shard_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cuddle_merge_topk_ordered": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -17,6 +17,7 @@
 
 #include "cuddle_kernels.hpp"
 #include "cuddle_route.hpp"
+#include "cuddle_shard.hpp"
 #include "cuddle_rabitq.hpp"
 
 using namespace cuddle;
@@ -115,6 +116,9 @@ struct Plan {
     // (query, parent) pairs of the grouped routing level
     uint32_t *pair_info = nullptr, *pair_parent = nullptr, *pair_sorted = nullptr, *small_flag = nullptr;
     uint32_t *grp_cnt = nullptr, *grp_poff = nullptr, *grp_ioff = nullptr, *grp_fill = nullptr, *grp_item = nullptr;
+    // leaf-sharded exact selection: threshold/budget per query, global order key of every selected candidate
+    uint32_t *thr = nullptr;
+    uint64_t *sel_ord = nullptr;
     uint32_t *sel_pos = nullptr, *sel_key = nullptr, *sel_count = nullptr, *cand_count = nullptr;
     float *sel_dist = nullptr;
     // MFMA routing
@@ -153,11 +157,16 @@ struct cuddle_index {
     std::mutex mu;
     // stage timing of the last timed search
     std::vector<hipEvent_t> events;
+    std::vector<int> event_stage; // stage whose work follows the event on the stream, or -1
     size_t events_used = 0;
     bool timed = false;
     uint32_t timed_searches = 0;
     hipStream_t last_stream = nullptr;
     uint32_t last_levels = 0;
+    // leaf-sharded exact search: the plan of the batch between cuddle_shard_scan and cuddle_shard_finish
+    Plan shard_plan;
+    uint32_t shard_nq = 0;
+    int shard_state = 0; // 0 idle, 1 scanned, 2 ties counted
     ~cuddle_index() {
         for (void *p : owned) (void)hipFree(p);
         ws.release();
@@ -197,7 +206,7 @@ static GroupedKernel grouped_kernel_for(uint32_t dim, uint32_t metric) {
 
 using ScanKernel = void (*)(IndexDev, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, uint32_t,
                             uint32_t, uint32_t, void *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *,
-                            const uint32_t *);
+                            const uint32_t *, uint32_t *);
 
 // The Hamming scan instantiation for a code of `words` u64 (distances in u8 when dim < 255).
 static ScanKernel scan_kernel_for(uint32_t dim, uint32_t words) {
@@ -631,6 +640,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     size_t o_pi = carve(qc * pl.probes * 4), o_pp = carve(qc * pl.probes * 4), o_ps = carve(qc * pl.probes * 4);
     size_t o_sf = carve(qc * 4), o_gc = carve(gw * 4), o_gp = carve(gw * 4), o_gi = carve(gw * 4), o_gf = carve(gw * 4);
     size_t o_git = carve((qc * pl.probes / kGroupPairs + gw + 1) * 16);
+    size_t o_thr = carve(qc * 8), o_sord = carve(qc * pl.sstride * 8);
     pl.bytes = off;
     ST_TRY(ix->ws.ensure(pl.bytes));
     char *b = static_cast<char *>(ix->ws.p);
@@ -651,6 +661,8 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     pl.grp_cnt = (uint32_t *)(b + o_gc); pl.grp_poff = (uint32_t *)(b + o_gp); pl.grp_ioff = (uint32_t *)(b + o_gi);
     pl.grp_fill = (uint32_t *)(b + o_gf);
     pl.grp_item = (uint32_t *)(b + o_git);
+    pl.thr = (uint32_t *)(b + o_thr);
+    pl.sel_ord = (uint64_t *)(b + o_sord);
     return CUDDLE_OK;
 }
 
@@ -666,13 +678,16 @@ static cuddle_status rerank_k_of(uint32_t k, uint32_t rf, uint32_t flags, uint64
 // ---------------------------------------------------------------------------------------------
 // stage launchers (device pointers, asynchronous on `s`)
 // ---------------------------------------------------------------------------------------------
-static void mark(cuddle_index *ix, hipStream_t s) {
+// Records an event; `stage` names the work enqueued between it and the next event (-1: none).
+static void mark(cuddle_index *ix, hipStream_t s, int stage) {
     if (!ix->timed) return;
     if (ix->events_used == ix->events.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return;
         ix->events.push_back(e);
+        ix->event_stage.push_back(-1);
     }
+    ix->event_stage[ix->events_used] = stage;
     (void)hipEventRecord(ix->events[ix->events_used++], s);
 }
 
@@ -840,7 +855,9 @@ extern "C" int cuddle_debug_stamps(uint64_t *out, uint32_t n_blocks) {
 #endif
 
 // Scan + phase-1 selection for the leaf lists in pl.leaves / pl.lcount.
-static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32_t nq, hipStream_t s) {
+// ghist != null: histogram mode (distances to the spill buffer, local histograms out, no selection).
+static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32_t nq, hipStream_t s,
+                                        uint32_t *ghist = nullptr) {
     const IndexDev &v = ix->dev;
     // longest queries first (nq <= kMaxChunk = 4096 fits one sorting block)
     hipLaunchKernelGGL(cand_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, pl.leaves, pl.lstride, pl.lcount, nq,
@@ -859,7 +876,7 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
     }
     hipLaunchKernelGGL(scan_kernel_for(v.dim, v.words), dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, pl.qcodes,
                        pl.leaves, pl.lstride, pl.lcount, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, (void *)pl.gdist,
-                       pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, pl.order);
+                       pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, pl.order, ghist);
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
 }
@@ -873,11 +890,12 @@ static cuddle_status launch_rerank(cuddle_index *ix, const Plan &pl, const float
 }
 
 static cuddle_status launch_topk(cuddle_index *ix, const Plan &pl, uint32_t nq, uint64_t *d_ids, float *d_dist,
-                                 uint32_t *d_count, hipStream_t s) {
+                                 uint32_t *d_count, hipStream_t s, uint64_t *d_order = nullptr) {
     const IndexDev &v = ix->dev;
     size_t lds = (size_t)host_next_pow2(pl.sstride) * 8;
     hipLaunchKernelGGL(topk_kernel, dim3(nq), dim3(256), lds, s, v, pl.sel_pos, pl.sel_key, pl.sel_dist, pl.sstride,
-                       pl.sel_count, pl.k, v.code_kind == CUDDLE_CODE_RABITQ ? 1u : 0u, d_ids, d_dist, d_count);
+                       pl.sel_count, pl.k, v.code_kind == CUDDLE_CODE_RABITQ ? 1u : 0u, d_ids, d_dist, d_count,
+                       d_order ? pl.sel_ord : nullptr, d_order);
     hipLaunchKernelGGL(stats_accum_kernel, dim3(std::min<uint32_t>((nq + 255) / 256, 8)), dim3(256), 0, s, pl.lcount, pl.cand_count,
                        pl.sel_count, nq, ix->d_stats);
     HIP_TRY(hipGetLastError());
@@ -894,6 +912,7 @@ static cuddle_status search_device_locked(cuddle_index *ix, const float *dq, uin
     uint64_t rerank_k;
     ST_TRY(rerank_k_of(k, rf, flags, rerank_k));
     ix->timed = (flags & CUDDLE_SEARCH_TIME_STAGES) != 0 && ix->events_used + 4096 < kMaxEvents;
+    ix->shard_state = 0; // the work space is about to be re-planned: an unfinished sharded batch is void
     ix->last_stream = s;
     ix->last_levels = ix->n_levels;
     HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
@@ -904,17 +923,17 @@ static cuddle_status search_device_locked(cuddle_index *ix, const float *dq, uin
     for (uint32_t q0 = 0; q0 < nq; q0 += pl.qc) {
         const uint32_t qc = std::min(pl.qc, nq - q0);
         const float *q = dq + (uint64_t)q0 * dim;
-        mark(ix, s);
+        mark(ix, s, CUDDLE_STAGE_QUANTIZE);
         ST_TRY(launch_quantize(ix, pl, q, qc, s));
-        mark(ix, s);
+        mark(ix, s, CUDDLE_STAGE_ROUTE);
         ST_TRY(launch_route(ix, pl, q, qc, flags, s));
-        mark(ix, s);
+        mark(ix, s, CUDDLE_STAGE_SCAN);
         ST_TRY(launch_scan_select(ix, pl, qc, s));
-        mark(ix, s);
+        mark(ix, s, CUDDLE_STAGE_RERANK);
         ST_TRY(launch_rerank(ix, pl, q, qc, s));
-        mark(ix, s);
+        mark(ix, s, CUDDLE_STAGE_TOPK);
         ST_TRY(launch_topk(ix, pl, qc, d_ids + (uint64_t)q0 * k, d_dist + (uint64_t)q0 * k, d_count ? d_count + q0 : nullptr, s));
-        mark(ix, s);
+        mark(ix, s, -1);
     }
     return CUDDLE_OK;
 }
@@ -962,13 +981,13 @@ extern "C" cuddle_status cuddle_stage_times(cuddle_index *idx, float *ms, uint32
     const size_t used = idx->events_used;
     idx->events_used = 0;
     HIP_TRY(hipEventSynchronize(idx->events[used - 1]));
-    const size_t per = CUDDLE_STAGE_COUNT + 1;
-    for (size_t c = 0; c + per <= used; c += per)
-        for (int sidx = 0; sidx < CUDDLE_STAGE_COUNT; ++sidx) {
-            float t = 0.f;
-            HIP_TRY(hipEventElapsedTime(&t, idx->events[c + sidx], idx->events[c + sidx + 1]));
-            ms[sidx] += t;
-        }
+    for (size_t c = 0; c + 1 < used; ++c) {
+        const int st = idx->event_stage[c];
+        if (st < 0 || st >= CUDDLE_STAGE_COUNT) continue;
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, idx->events[c], idx->events[c + 1]));
+        ms[st] += t;
+    }
     return CUDDLE_OK;
 }
 
@@ -1268,8 +1287,132 @@ extern "C" cuddle_status cuddle_search_leaves_batch(cuddle_index *idx, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
+// leaf-sharded exact search: cuddle_search_batch_device split where the shards must agree
+// ---------------------------------------------------------------------------------------------
+extern "C" cuddle_status cuddle_shard_scan(cuddle_index *idx, const float *d_queries, uint32_t n_queries, uint32_t dim,
+                                           uint32_t k, uint32_t probes_per_level, uint32_t rerank_factor, uint32_t flags,
+                                           uint32_t *d_hist, uint32_t *leaf_stride, void *stream) {
+    if (!idx || !d_queries || !d_hist) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    idx->shard_state = 0;
+    if (idx->dev.code_kind != CUDDLE_CODE_BINARY) return fail(CUDDLE_ERR_UNSUPPORTED, "sharded exact selection needs binary codes");
+    if (dim != idx->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, idx->dev.dim);
+    if (probes_per_level == 0) return fail(CUDDLE_ERR_BAD_ARG, "probes_per_level must be >= 1");
+    if (n_queries == 0 || n_queries > kMaxChunk) return fail(CUDDLE_ERR_UNSUPPORTED, "1..%u queries per sharded batch", kMaxChunk);
+    uint64_t rerank_k;
+    ST_TRY(rerank_k_of(k, rerank_factor, flags, rerank_k));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    idx->timed = (flags & CUDDLE_SEARCH_TIME_STAGES) != 0 && idx->events_used + 4096 < kMaxEvents;
+    idx->last_stream = s;
+    idx->last_levels = idx->n_levels;
+    HIP_TRY(hipMemsetAsync(idx->d_stats, 0, sizeof(DevStats), s));
+    Plan &pl = idx->shard_plan;
+    pl = Plan();
+    ST_TRY(make_plan(idx, n_queries, k, probes_per_level, rerank_k, 0, pl));
+    if (idx->timed) idx->timed_searches++;
+    mark(idx, s, CUDDLE_STAGE_QUANTIZE);
+    ST_TRY(launch_quantize(idx, pl, d_queries, n_queries, s));
+    mark(idx, s, CUDDLE_STAGE_ROUTE);
+    ST_TRY(launch_route(idx, pl, d_queries, n_queries, flags, s));
+    mark(idx, s, CUDDLE_STAGE_SCAN);
+    ST_TRY(launch_scan_select(idx, pl, n_queries, s, d_hist));
+    mark(idx, s, -1);
+    idx->shard_nq = n_queries;
+    idx->shard_state = 1;
+    if (leaf_stride) *leaf_stride = pl.lstride;
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_shard_ties(cuddle_index *idx, const uint32_t *d_global_hist, uint32_t *d_tie_count,
+                                           void *stream) {
+    if (!idx || !d_global_hist || !d_tie_count) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    if (idx->shard_state != 1) return fail(CUDDLE_ERR_BAD_ARG, "cuddle_shard_ties must follow cuddle_shard_scan");
+    const Plan &pl = idx->shard_plan;
+    const IndexDev &v = idx->dev;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = scan_lds_bytes(v.dim, v.words, pl.lstride, 0, 0);
+    mark(idx, s, CUDDLE_STAGE_SCAN); // the selection steps count as scan time
+    if (v.dim < 255)
+        hipLaunchKernelGGL(shard_ties_kernel<uint8_t>, dim3(idx->shard_nq), dim3(256), lds, s, v, pl.leaves, pl.lstride, pl.lcount,
+                           pl.lstride, d_global_hist, pl.rerank_k, (const void *)pl.gdist, pl.cstride, pl.thr, d_tie_count);
+    else
+        hipLaunchKernelGGL(shard_ties_kernel<uint16_t>, dim3(idx->shard_nq), dim3(256), lds, s, v, pl.leaves, pl.lstride, pl.lcount,
+                           pl.lstride, d_global_hist, pl.rerank_k, (const void *)pl.gdist, pl.cstride, pl.thr, d_tie_count);
+    HIP_TRY(hipGetLastError());
+    mark(idx, s, -1);
+    idx->shard_state = 2;
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_shard_finish(cuddle_index *idx, const float *d_queries, const uint32_t *d_global_ties,
+                                             uint64_t *d_out_ids, float *d_out_dist, uint64_t *d_out_order,
+                                             uint32_t *d_out_count, void *stream) {
+    if (!idx || !d_queries || !d_global_ties || !d_out_ids || !d_out_dist || !d_out_order)
+        return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    if (idx->shard_state != 2) return fail(CUDDLE_ERR_BAD_ARG, "cuddle_shard_finish must follow cuddle_shard_ties");
+    const Plan &pl = idx->shard_plan;
+    const IndexDev &v = idx->dev;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t nq = idx->shard_nq;
+    const size_t lds = scan_lds_bytes(v.dim, v.words, pl.lstride, 0, 0);
+    mark(idx, s, CUDDLE_STAGE_SCAN);
+    if (v.dim < 255)
+        hipLaunchKernelGGL(shard_select_kernel<uint8_t>, dim3(nq), dim3(256), lds, s, v, pl.leaves, pl.lstride, pl.lcount,
+                           pl.lstride, pl.thr, d_global_ties, (const void *)pl.gdist, pl.cstride, pl.sel_pos, pl.sel_key,
+                           pl.sel_ord, pl.sstride, pl.sel_count);
+    else
+        hipLaunchKernelGGL(shard_select_kernel<uint16_t>, dim3(nq), dim3(256), lds, s, v, pl.leaves, pl.lstride, pl.lcount,
+                           pl.lstride, pl.thr, d_global_ties, (const void *)pl.gdist, pl.cstride, pl.sel_pos, pl.sel_key,
+                           pl.sel_ord, pl.sstride, pl.sel_count);
+    HIP_TRY(hipGetLastError());
+    mark(idx, s, CUDDLE_STAGE_RERANK);
+    ST_TRY(launch_rerank(idx, pl, d_queries, nq, s));
+    mark(idx, s, CUDDLE_STAGE_TOPK);
+    ST_TRY(launch_topk(idx, pl, nq, d_out_ids, d_out_dist, d_out_count, s, d_out_order));
+    mark(idx, s, -1);
+    idx->shard_state = 0;
+    return CUDDLE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // multi-GPU merge (host)
 // ---------------------------------------------------------------------------------------------
+extern "C" cuddle_status cuddle_merge_topk_ordered(const uint64_t *lists_ids, const float *lists_dist,
+                                                   const uint64_t *lists_order, uint32_t n_lists, uint32_t n_queries,
+                                                   uint32_t k, uint64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    if (!lists_ids || !lists_dist || !lists_order || !out_ids || !out_dist) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    if (k == 0 || n_lists == 0) return fail(CUDDLE_ERR_BAD_ARG, "k and n_lists must be >= 1");
+    struct Item { float d; uint64_t order, id; };
+    std::vector<Item> items;
+    items.reserve((size_t)n_lists * k);
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        items.clear();
+        for (uint32_t l = 0; l < n_lists; ++l)
+            for (uint32_t r = 0; r < k; ++r) {
+                size_t o = ((size_t)l * n_queries + q) * k + r;
+                if (lists_ids[o] == UINT64_MAX) break;
+                items.push_back({lists_dist[o], lists_order[o], lists_ids[o]});
+            }
+        std::sort(items.begin(), items.end(), [](const Item &a, const Item &b) {
+            if (a.d < b.d) return true;
+            if (a.d > b.d) return false;
+            return a.order < b.order;
+        });
+        uint32_t n = (uint32_t)std::min<size_t>(items.size(), k);
+        for (uint32_t i = 0; i < k; ++i) {
+            out_ids[(size_t)q * k + i] = i < n ? items[i].id : UINT64_MAX;
+            out_dist[(size_t)q * k + i] = i < n ? items[i].d : std::numeric_limits<float>::infinity();
+        }
+        if (out_count) out_count[q] = n;
+    }
+    return CUDDLE_OK;
+}
+
 extern "C" cuddle_status cuddle_merge_topk(const uint64_t *lists_ids, const float *lists_dist, uint32_t n_lists,
                                            uint32_t n_queries, uint32_t k, uint64_t *out_ids, float *out_dist,
                                            uint32_t *out_count) {

@@ -903,7 +903,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(CUDDLE
 scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *leaves, uint32_t lstride,
                            const uint32_t *lcount, uint32_t lcap, uint32_t tcap, uint32_t rerank_k, uint32_t dist_cap,
                            void *gdist_v, uint32_t gdist_stride, uint32_t *sel_pos, uint32_t *sel_key,
-                           uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count, const uint32_t *order) {
+                           uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count, const uint32_t *order,
+                           uint32_t *ghist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t q = order ? order[blockIdx.x] : blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
@@ -918,10 +919,15 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
     if (tid == 0) cand_count[q] = C;
     if (C == 0) {
         if (tid == 0) sel_count[q] = 0;
+        if (ghist)
+            for (uint32_t i = tid; i <= D; i += blockDim.x) ghist[(uint64_t)q * (D + 1) + i] = 0;
         return;
     }
     CUDDLE_STAMP(1, 1);
-    DistT *dist = C <= dist_cap ? reinterpret_cast<DistT *>(s.dist)
+    // histogram mode (ghist != null, leaf-sharded search): distances go to the spill buffer and the
+    // kernel ends after phase 1 with the query's local histogram; the selection follows once the
+    // histograms of all shards are summed (cuddle_shard.hpp)
+    DistT *dist = (C <= dist_cap && !ghist) ? reinterpret_cast<DistT *>(s.dist)
                                    : reinterpret_cast<DistT *>(gdist_v) + (uint64_t)q * gdist_stride;
     // phase 1
     if (PAIRS > 0) {
@@ -939,6 +945,10 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
     }
     __syncthreads();
     CUDDLE_STAMP(1, 2);
+    if (ghist) {
+        for (uint32_t i = tid; i <= D; i += blockDim.x) ghist[(uint64_t)q * (D + 1) + i] = s.hist[i];
+        return;
+    }
     // phase 2
     uint32_t T, budget;
     if (C <= rerank_k) {
@@ -1061,7 +1071,7 @@ rerank_kernel(IndexDev ix, const float *queries, const uint32_t *sel_pos, uint32
 __global__ void __launch_bounds__(256)
 topk_kernel(IndexDev ix, const uint32_t *sel_pos, const uint32_t *sel_key, const float *sel_dist,
             uint32_t sel_stride, const uint32_t *sel_count, uint32_t k, uint32_t key_is_rank, uint64_t *out_ids,
-            float *out_dist, uint32_t *out_count) {
+            float *out_dist, uint32_t *out_count, const uint64_t *sel_ord, uint64_t *out_order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
@@ -1085,9 +1095,11 @@ topk_kernel(IndexDev ix, const uint32_t *sel_pos, const uint32_t *sel_key, const
             uint32_t j = (uint32_t)(skeys[i] & 0x3FFFu);
             out_ids[(uint64_t)q * k + i] = ix.ids[sp[j]];
             out_dist[(uint64_t)q * k + i] = sd[j];
+            if (out_order) out_order[(uint64_t)q * k + i] = sel_ord[(uint64_t)q * sel_stride + j];
         } else {
             out_ids[(uint64_t)q * k + i] = ~0ull;
             out_dist[(uint64_t)q * k + i] = __builtin_inff();
+            if (out_order) out_order[(uint64_t)q * k + i] = ~0ull;
         }
     }
     if (tid == 0 && out_count) out_count[q] = nout;

@@ -1,0 +1,147 @@
+// cuddle_shard.hpp — exact phase-1 selection over leaf shards.
+//
+// A leaf-sharded index answers a batch with every rank routing all queries (the tree is
+// replicated) and scanning only the leaves it owns. The selection of the rerank_k best candidates
+// (select_top_candidates, src/index/hierarchical.rs:645-655) is a property of ALL candidates of a
+// query, so the single-index result is reproduced exactly by splitting the scan kernel at the two
+// points where the ranks must agree:
+//   1. scan (scan_select_hamming_kernel in histogram mode): local Hamming distances -> spill
+//      buffer, local (dim+1)-bin histogram -> summed over ranks by the caller;
+//   2. shard_ties_kernel: threshold T and tie budget from the global histogram; number of local
+//      candidates at distance T per leaf slot -> summed over ranks (a leaf has one owner, so the
+//      sum is just the union);
+//   3. shard_select_kernel: every rank keeps its candidates below T and, of its ties, those whose
+//      position among ALL ties (leaf slot order, then in-leaf order) is below the budget.
+// The union of the ranks' selections is then exactly the single-index selection, and the merge of
+// the ranks' top-k by (distance, Hamming distance, leaf slot, in-leaf position) is its top-k.
+#pragma once
+
+#include "cuddle_kernels.hpp"
+
+namespace cuddle {
+
+// thr[2q] = T, thr[2q+1] = budget; tie_count[q][slot] = local candidates of the slot at distance T
+// (0 for slots past the query's leaf list). One block per query; dynamic LDS =
+// scan_lds_bytes(dim, words, lcap, 0, 0).
+template <class DistT>
+__global__ void __launch_bounds__(256)
+shard_ties_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const uint32_t *lcount, uint32_t lcap,
+                  const uint32_t *global_hist, uint32_t rerank_k, const void *gdist_v, uint32_t gdist_stride,
+                  uint32_t *thr, uint32_t *tie_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const uint32_t D = ix.dim;
+    ScanLds s = scan_lds_carve(smem, D, ix.words, lcap, 0);
+    const uint32_t nl = min(lcount[q], lcap);
+    for (uint32_t i = tid; i <= D; i += blockDim.x) s.hist[i] = global_hist[(uint64_t)q * (D + 1) + i];
+    scan_load_leaves(ix, s, leaves + (uint64_t)q * lstride, nl, 0, nullptr); // barriers inside: hist visible after
+    if (w == 0) { // smallest T with #(<= T) >= rerank_k over ALL shards; none: every candidate is selected
+        uint32_t carry = 0, T = D + 1, budget = 0;
+        bool done = false;
+        for (uint32_t b0 = 0; b0 <= D && !done; b0 += 64) {
+            const uint32_t b = b0 + lane;
+            const uint32_t v = b <= D ? s.hist[b] : 0;
+            const uint32_t incl = wave_inclusive_sum(v) + carry;
+            const uint64_t hit = __ballot(incl >= rerank_k);
+            if (hit) {
+                const uint32_t first = __ffsll((unsigned long long)hit) - 1;
+                const uint32_t incl_f = __shfl(incl, first, 64), v_f = __shfl(v, first, 64);
+                T = b0 + first;
+                budget = rerank_k - (incl_f - v_f);
+                done = true;
+            }
+            carry = __shfl(incl, 63, 64);
+        }
+        if (lane == 0) {
+            s.misc[0] = T;
+            s.misc[1] = budget;
+            thr[2 * q] = T;
+            thr[2 * q + 1] = budget;
+        }
+    }
+    __syncthreads();
+    const uint32_t T = s.misc[0];
+    const DistT *dist = reinterpret_cast<const DistT *>(gdist_v) + (uint64_t)q * gdist_stride;
+    for (uint32_t sl = w; sl < lstride; sl += nw) {
+        uint32_t cnt = 0;
+        if (sl < nl) {
+            const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base;
+            for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                cnt += __popcll(__ballot(i < n && (uint32_t)dist[base + (i < n ? i : 0)] == T));
+            }
+        }
+        if (lane == 0) tie_count[(uint64_t)q * lstride + sl] = cnt;
+    }
+}
+
+// The rank's share of the selection, in scan order: sel_pos (leaf-contiguous position), sel_key
+// (Hamming distance), sel_ord (the candidate's place in the global phase-1 order:
+// Hamming << 48 | leaf slot << 24 | in-leaf position). One block per query; same LDS as above.
+template <class DistT>
+__global__ void __launch_bounds__(256)
+shard_select_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const uint32_t *lcount, uint32_t lcap,
+                    const uint32_t *thr, const uint32_t *global_ties, const void *gdist_v, uint32_t gdist_stride,
+                    uint32_t *sel_pos, uint32_t *sel_key, uint64_t *sel_ord, uint32_t sel_stride, uint32_t *sel_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    ScanLds s = scan_lds_carve(smem, ix.dim, ix.words, lcap, 0);
+    const uint32_t nl = min(lcount[q], lcap);
+    const uint32_t T = thr[2 * q], budget = thr[2 * q + 1];
+    scan_load_leaves(ix, s, leaves + (uint64_t)q * lstride, nl, 0, nullptr);
+    // ties before each slot, over all shards (s.ltile is free: no tiles are cut here)
+    __syncthreads();
+    for (uint32_t sl = tid; sl < nl; sl += blockDim.x) s.ltile[sl] = global_ties[(uint64_t)q * lstride + sl];
+    __syncthreads();
+    wave0_exclusive_scan_lds(s.ltile, nl);
+    __syncthreads();
+    const DistT *dist = reinterpret_cast<const DistT *>(gdist_v) + (uint64_t)q * gdist_stride;
+    uint32_t *sel_off = s.lcode; // codes are not read here: the slot's first output rank
+    auto quota_of = [&](uint32_t sl) -> uint32_t { // how many of the slot's ties are inside the budget
+        const uint32_t before = s.ltile[sl], ties = s.ltile[sl + 1] - before;
+        return before >= budget ? 0u : min(ties, budget - before);
+    };
+    for (uint32_t sl = w; sl < nl; sl += nw) {
+        const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base;
+        uint32_t lt = 0;
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            lt += __popcll(__ballot(i < n && (uint32_t)dist[base + (i < n ? i : 0)] < T));
+        }
+        if (lane == 0) sel_off[sl] = n ? lt + quota_of(sl) : 0u; // a leaf has one owner: its ties are all here or all elsewhere
+    }
+    __syncthreads();
+    wave0_exclusive_scan_lds(sel_off, nl);
+    __syncthreads();
+    uint32_t *sp = sel_pos + (uint64_t)q * sel_stride, *sk = sel_key + (uint64_t)q * sel_stride;
+    uint64_t *so = sel_ord + (uint64_t)q * sel_stride;
+    const uint64_t lm = lanemask_lt();
+    for (uint32_t sl = w; sl < nl; sl += nw) {
+        const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base;
+        if (n == 0) continue;
+        const uint32_t quota = quota_of(sl);
+        uint32_t out = sel_off[sl], tie_run = 0;
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool in = i < n;
+            const uint32_t kv = in ? (uint32_t)dist[base + i] : 0xFFFFFFFFu;
+            const bool tie = in && kv == T;
+            const uint64_t tb = __ballot(tie);
+            const bool flag = in && (kv < T || (tie && tie_run + (uint32_t)__popcll(tb & lm) < quota));
+            const uint64_t fb = __ballot(flag);
+            if (flag) {
+                const uint32_t r = out + (uint32_t)__popcll(fb & lm);
+                if (r < sel_stride) {
+                    sp[r] = s.lbeg[sl] + i;
+                    sk[r] = kv;
+                    so[r] = ((uint64_t)kv << 48) | ((uint64_t)sl << 24) | i;
+                }
+            }
+            tie_run += __popcll(tb);
+            out += __popcll(fb);
+        }
+    }
+    if (tid == 0) sel_count[q] = min(sel_off[nl], sel_stride);
+}
+
+} // namespace cuddle

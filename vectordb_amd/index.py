@@ -113,6 +113,59 @@ class DeviceIndex:
             C.c_void_p(stream)))
         return out_ids, out_dist, out_count
 
+    # ---- leaf-sharded exact search: the three steps between which the shards exchange counts ----
+    def shard_scan(self, d_queries, k: int, probes_per_level: int, rerank_factor: int, flags: int = 0,
+                   stream: Optional[int] = None):
+        """Step 1 on this shard: returns the shard's Hamming histogram, int32 CUDA tensor
+        [nq, dim + 1], to be summed over the shards."""
+        import torch
+
+        assert d_queries.is_cuda and d_queries.dtype == torch.float32 and d_queries.is_contiguous()
+        nq, dim = d_queries.shape
+        if stream is None:
+            stream = torch.cuda.current_stream(d_queries.device).cuda_stream
+        hist = torch.empty((nq, dim + 1), dtype=torch.int32, device=d_queries.device)
+        stride = C.c_uint32(0)
+        _ffi.check(self._lib.cuddle_shard_scan(self._handle, C.c_void_p(d_queries.data_ptr()), nq, dim, k, probes_per_level,
+                                               rerank_factor, flags, C.c_void_p(hist.data_ptr()), C.byref(stride),
+                                               C.c_void_p(stream)))
+        self._shard = (nq, k, int(stride.value))
+        return hist
+
+    def shard_ties(self, global_hist, stream: Optional[int] = None):
+        """Step 2: `global_hist` = the histograms summed over all shards. Returns this shard's tie
+        counts per leaf slot, int32 CUDA tensor [nq, leaf_stride], to be summed likewise."""
+        import torch
+
+        nq, _, stride = self._shard
+        if stream is None:
+            stream = torch.cuda.current_stream(global_hist.device).cuda_stream
+        assert global_hist.is_contiguous() and global_hist.dtype == torch.int32
+        ties = torch.empty((nq, stride), dtype=torch.int32, device=global_hist.device)
+        _ffi.check(self._lib.cuddle_shard_ties(self._handle, C.c_void_p(global_hist.data_ptr()), C.c_void_p(ties.data_ptr()),
+                                               C.c_void_p(stream)))
+        return ties
+
+    def shard_finish(self, d_queries, global_ties, stream: Optional[int] = None):
+        """Step 3: returns (ids int64 view of u64, dist f32, order int64 view of u64, count int32),
+        each [nq, k] / [nq]: this shard's top-k of the global selection."""
+        import torch
+
+        nq, k, _ = self._shard
+        dev = d_queries.device
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        assert global_ties.is_contiguous() and global_ties.dtype == torch.int32
+        ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        order = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        count = torch.empty((nq,), dtype=torch.int32, device=dev)
+        _ffi.check(self._lib.cuddle_shard_finish(self._handle, C.c_void_p(d_queries.data_ptr()),
+                                                 C.c_void_p(global_ties.data_ptr()), C.c_void_p(ids.data_ptr()),
+                                                 C.c_void_p(dist.data_ptr()), C.c_void_p(order.data_ptr()),
+                                                 C.c_void_p(count.data_ptr()), C.c_void_p(stream)))
+        return ids, dist, order, count
+
     def last_stats(self) -> dict:
         st = _ffi.Stats()
         _ffi.check(self._lib.cuddle_last_stats(self._handle, C.byref(st)))

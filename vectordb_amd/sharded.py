@@ -9,9 +9,20 @@ a few hundred KB, latency-bound on the fully connected xGMI links — followed b
 that every rank performs identically (ties: distance, then rank, then position in the rank's
 list; the same rule as `cuddle_merge_topk`).
 
-Each rank selects its own top rerank_k candidates among its leaves, so up to world * rerank_k
-candidates are reranked in total: recall is >= the single-index recall, and the result equals the
-single-index search exactly whenever rerank_k covers every candidate.
+Two variants:
+
+* `ShardedSearcher` (simple): each rank selects its own top rerank_k candidates among its leaves,
+  so up to world * rerank_k candidates are reranked in total: recall is >= the single-index recall,
+  and the result equals the single-index search exactly whenever rerank_k covers every candidate.
+  One collective per batch (the all-gather).
+
+* `ExactShardedSearcher`: reproduces the single-index result bit for bit. The selection of the
+  rerank_k best candidates is a property of all candidates of a query, so the ranks agree on it
+  with two small all-reduces before reranking: the per-query Hamming histograms ([nq, dim+1] u32)
+  give the global threshold and tie budget, the per-leaf-slot tie counts ([nq, leaf_stride] u32)
+  decide which ties at the threshold are inside the budget. Every rank then reranks only its
+  members of the global selection (rerank_k candidates in total, not world * rerank_k) and the
+  all-gathered lists are merged by (distance, global phase-1 order).
 """
 from __future__ import annotations
 
@@ -64,3 +75,69 @@ class ShardedSearcher:
         dist.all_gather(list(all_ids.unbind(0)), ids.contiguous(), group=self.group)
         dist.all_gather(list(all_dist.unbind(0)), dist_.contiguous(), group=self.group)
         return merge_gathered(all_ids, all_dist, k)
+
+
+def merge_gathered_ordered(all_ids: torch.Tensor, all_dist: torch.Tensor, all_order: torch.Tensor, k: int):
+    """all_*: [world, nq, k]. Ascending by (distance, order), the rule of cuddle_merge_topk_ordered.
+    Returns (ids [nq,k], dist [nq,k], count [nq])."""
+    world, nq, kk = all_dist.shape
+    d = all_dist.permute(1, 0, 2).reshape(nq, world * kk)
+    i = all_ids.permute(1, 0, 2).reshape(nq, world * kk)
+    o = all_order.permute(1, 0, 2).reshape(nq, world * kk)
+    pad = i == PAD_ID
+    d = torch.where(pad, torch.full_like(d, float("inf")), d)
+    # order keys are u64 seen through int64; their top bit is clear (Hamming < 2^15), pads sort last
+    o = torch.where(pad, torch.full_like(o, torch.iinfo(torch.int64).max), o)
+    _, p1 = torch.sort(o, dim=1, stable=True)          # secondary key first ...
+    d1, i1 = torch.gather(d, 1, p1), torch.gather(i, 1, p1)
+    sd, p2 = torch.sort(d1, dim=1, stable=True)        # ... then a stable sort by the primary key
+    si = torch.gather(i1, 1, p2)
+    sd, si = sd[:, :k].contiguous(), si[:, :k].contiguous()
+    count = (si != PAD_ID).sum(dim=1).to(torch.int32)
+    return si, sd, count
+
+
+class ExactShardedSearcher:
+    """Bit-exact leaf-sharded search. `engine` is this rank's shard and provides
+    shard_scan(queries, k, probes, rf) -> hist, shard_ties(global_hist) -> ties,
+    shard_finish(queries, global_ties) -> (ids, dist, order, count) as tensors on the collective's
+    device (`DeviceIndex` on the GPU)."""
+
+    def __init__(self, engine, group: Optional[dist.ProcessGroup] = None):
+        self.engine = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def search_batch(self, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int):
+        hist = self.engine.shard_scan(queries, k, probes_per_level, rerank_factor)
+        if self.world > 1:
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=self.group)
+        ties = self.engine.shard_ties(hist)
+        if self.world > 1:
+            dist.all_reduce(ties, op=dist.ReduceOp.SUM, group=self.group)
+        ids, dist_, order, count = self.engine.shard_finish(queries, ties)
+        if self.world == 1:
+            return ids, dist_, count
+        nq = ids.shape[0]
+        all_ids = torch.empty((self.world, nq, k), dtype=ids.dtype, device=ids.device)
+        all_dist = torch.empty((self.world, nq, k), dtype=dist_.dtype, device=dist_.device)
+        all_order = torch.empty((self.world, nq, k), dtype=order.dtype, device=order.device)
+        dist.all_gather(list(all_ids.unbind(0)), ids.contiguous(), group=self.group)
+        dist.all_gather(list(all_dist.unbind(0)), dist_.contiguous(), group=self.group)
+        dist.all_gather(list(all_order.unbind(0)), order.contiguous(), group=self.group)
+        return merge_gathered_ordered(all_ids, all_dist, all_order, k)
+
+
+def exact_search_in_process(engines, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int):
+    """The ExactShardedSearcher protocol over several shards held by ONE process (sums instead of
+    all-reduces): for tests and for single-GPU rehearsals of an N-way split."""
+    hists = [e.shard_scan(queries, k, probes_per_level, rerank_factor) for e in engines]
+    ghist = torch.stack(hists).sum(dim=0).to(torch.int32).contiguous()
+    ties = [e.shard_ties(ghist) for e in engines]
+    gties = torch.stack(ties).sum(dim=0).to(torch.int32).contiguous()
+    outs = [e.shard_finish(queries, gties) for e in engines]
+    all_ids = torch.stack([o[0] for o in outs])
+    all_dist = torch.stack([o[1] for o in outs])
+    all_order = torch.stack([o[2] for o in outs])
+    return merge_gathered_ordered(all_ids, all_dist, all_order, k)
