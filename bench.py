@@ -61,6 +61,11 @@ CONFIGS = {
                       rerank_sweep=[5, 10, 25, 50, 100, 200], code_kind="binary", tree=(100, 3, 125), gt_queries=1000,
                       label="one of 8 leaf shards of a synthetic 1B x 128 index: 125M x 128 integer-valued f32 "
                             "(2 GB codes + 64 GB fp32 in HBM), tree by construction (100-way x 3 levels, 125-vector leaves)"),
+    # config 3: RaBitQ codes, cosine, k = 100 (tree by construction: 46-way x 3 levels, 103-vector leaves = 10.03M vectors)
+    "rabitq10m": dict(n=46 ** 3 * 103, dim=768, n_queries=4096, k=100, metric="cosine", style="gauss", probes=100,
+                      rerank_sweep=[10, 20, 40], code_kind="rabitq", tree=(46, 3, 103), gt_queries=500,
+                      label="synthetic 10M x 768 f32 hierarchical Gaussian, RaBitQ codes (96 B + 8 B per vector), cosine, "
+                            "tree by construction (46-way x 3 levels, 103-vector leaves)"),
     "tiny": dict(n=20_000, dim=64, n_queries=256, k=10, metric="l2", style="gist", probes=8,
                  rerank_sweep=[5, 10, 25, 50, 100], branching=16, leaf=50, code_kind="binary", latent_dim=0,
                  label="tiny synthetic (20k x 64)"),
@@ -176,8 +181,11 @@ def main():
         assert world == 1, "the shard configs measure one GPU's share"
         fanout, levels, leaf_size = cfg["tree"]
         log(f"generating {cfg['label']}")
+        from vectordb_amd.builder import metric_id
         dti, queries = build_tree_index_on_device(cfg["dim"], fanout, levels, leaf_size, device, seed=0xC0DD1E,
-                                                  n_queries=cfg["n_queries"])
+                                                  n_queries=cfg["n_queries"], metric=metric_id(cfg["metric"]),
+                                                  style=cfg.get("style", "sift"),
+                                                  code_kind=_ffi.CODE_RABITQ if cfg["code_kind"] == "rabitq" else _ffi.CODE_BINARY)
         log("ground truth (GPU brute force) on a query sample")
         gq = cfg.get("gt_queries", cfg["n_queries"])
         gt = brute_force_topk(dti.vectors, queries[:gq], k, cfg["metric"], chunk=1 << 20).cpu().numpy()
@@ -303,7 +311,9 @@ def main():
     recall = recall_at_k(ids.cpu().numpy()[:len(gt)], gt, k)
 
     # ---- roofline of the dominant kernel (the Hamming scan + select) -----------------------------
-    code_bytes = 8 * ((cfg["dim"] + 63) // 64)
+    rabitq = cfg["code_kind"] == "rabitq"
+    code_bytes = (4 * ((cfg["dim"] + 31) // 32) + 8) if rabitq else 8 * ((cfg["dim"] + 63) // 64)
+    scan_kernel = "scan_select_rabitq_kernel" if rabitq else "scan_select_hamming_kernel"
     scan_bytes = stats["vectors_scanned"] * code_bytes           # algorithmic bytes of one launch (this rank)
     rerank_bytes = stats["vectors_reranked"] * 4 * cfg["dim"]
     n_timed = max(stage["searches"], 1)
@@ -313,9 +323,9 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", f"pmc_hbm_traffic_{args.config}.json")
     if world == 1 and os.path.exists(pmc_path):  # measured separately under rocprofv3 --pmc (it cannot run inside this process)
         pmc = json.load(open(pmc_path))
-        traffic = pmc["kernels"]["scan_select_hamming_kernel"]["traffic_bytes_per_launch"]
+        traffic = pmc["kernels"].get(scan_kernel, {}).get("traffic_bytes_per_launch")
         traffic_src = os.path.relpath(pmc_path, ROOT)
-    roofline = dict(bound="hbm", kernel="scan_select_hamming_kernel", achieved=achieved, peak=HBM_PEAK_GBPS,
+    roofline = dict(bound="hbm", kernel=scan_kernel, achieved=achieved, peak=HBM_PEAK_GBPS,
                     unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=scan_bytes, avg_launch_ms=scan_ms,
                     stage_ms_per_step={n: stage[n] / n_timed for n in _ffi.STAGE_NAMES},
@@ -335,7 +345,7 @@ def main():
 
     total_q = nq * args.steps
     out = {
-        "metric": "batched QPS at recall@10>=0.95",
+        "metric": f"batched QPS at recall@{k}>=0.95",
         "value": total_q / elapsed,
         "unit": "queries/s",
         "n_gpus": world,
@@ -345,13 +355,13 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "u64 xor/popcount scan + f32 rerank",
+        "dtype": "f32 sign-masked sums (RaBitQ estimator) + f32 rerank" if rabitq else "u64 xor/popcount scan + f32 rerank",
         "data": "synthetic",
-        "config": {"workload": cfg["label"] + f", L2, k={k}, {nq}-query batch, probes_per_level={probes}, "
+        "config": {"workload": cfg["label"] + f", {cfg['metric']}, k={k}, {nq}-query batch, probes_per_level={probes}, "
                                f"rerank_factor={chosen}" + (f", branching {cfg['branching']} / leaf {cfg['leaf']}" if "branching" in cfg else ""),
                    "name": args.config, "binary_threshold": args.threshold,
                    "parallelism": (f"leaf-sharded x{world}, {args.sharded} selection" if world > 1 else "single GPU")},
-        "recall_at_10": recall,
+        f"recall_at_{k}": recall,
         "recall_sweep": sweep,
         "p50_batch_ms": lat[len(lat) // 2],
         "p99_batch_ms": lat[min(len(lat) - 1, len(lat) * 99 // 100)],

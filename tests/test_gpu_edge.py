@@ -194,3 +194,20 @@ def test_device_array_index_matches_oracle(gpu):
     for i in range(q.shape[0]):
         r = oi.search(q[i].cpu().numpy(), 10, 4, 6)
         assert np.array_equal(ids[i], r["ids"]) and np.array_equal(dist[i].view(np.uint32), r["dist"].view(np.uint32)), i
+
+
+def test_device_array_rabitq_index_matches_oracle(gpu):
+    """The same with RaBitQ codes encoded on the GPU, cosine metric."""
+    from vectordb_amd.synthetic import build_tree_index_on_device
+
+    orc = _oracle()
+    dti, q = build_tree_index_on_device(dim=48, fanout=5, levels=3, leaf_size=30, device="cuda:0", seed=4, n_queries=40,
+                                        metric=_ffi.METRIC_COSINE, style="gauss", code_kind=_ffi.CODE_RABITQ)
+    dev = dti.create(gpu)
+    fi = dti.to_flat()
+    assert fi.n_vectors == 5 ** 3 * 30 and fi.code_kind == _ffi.CODE_RABITQ
+    ids, dist, cnt = dev.search_batch(q.cpu().numpy(), 10, 3, 5)
+    oi = orc.OracleIndex(fi)
+    for i in range(q.shape[0]):
+        r = oi.search(q[i].cpu().numpy(), 10, 3, 5)
+        assert np.array_equal(ids[i], r["ids"]) and np.array_equal(dist[i].view(np.uint32), r["dist"].view(np.uint32)), i

@@ -1,5 +1,5 @@
 """Per-phase timing of the blocks of one kernel. Needs a build of the library with
--DCUDDLE_STAMP_KERNEL=<id> (1 Hamming scan, 2 grouped routing distances, 3 register selection),
+-DCUDDLE_STAMP_KERNEL=<id> (1 Hamming scan, 2 grouped routing distances, 3 register selection, 6 RaBitQ scan),
 selected with CUDDLE_HIP_LIB; prints the mean time between consecutive stamps of a block, the block
 lifetime and the average number of blocks in flight. Development tool; not used by the tests or
 the benchmark.
@@ -30,8 +30,11 @@ def main():
     if "tree" in cfg:
         from vectordb_amd.synthetic import build_tree_index_on_device
         fanout, levels, leaf = cfg["tree"]
+        from vectordb_amd.builder import metric_id
         dti, queries = build_tree_index_on_device(cfg["dim"], fanout, levels, leaf, device, seed=0xC0DD1E,
-                                                  n_queries=cfg["n_queries"])
+                                                  n_queries=cfg["n_queries"], metric=metric_id(cfg["metric"]),
+                                                  style=cfg.get("style", "sift"),
+                                                  code_kind=_ffi.CODE_RABITQ if cfg["code_kind"] == "rabitq" else _ffi.CODE_BINARY)
         idx = dti.create(0)
     else:
         from vectordb_amd.builder import build_index

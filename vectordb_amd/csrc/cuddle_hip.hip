@@ -119,6 +119,7 @@ struct Plan {
     // leaf-sharded exact selection: threshold/budget per query, global order key of every selected candidate
     uint32_t *thr = nullptr;
     uint64_t *sel_ord = nullptr;
+    float *qnorm = nullptr; // cosine: sqrt(dot(q, q)) per query
     uint32_t *sel_pos = nullptr, *sel_key = nullptr, *sel_count = nullptr, *cand_count = nullptr;
     float *sel_dist = nullptr;
     // MFMA routing
@@ -183,7 +184,7 @@ static constexpr uint32_t kGemmMinWidth = 512; // narrower levels are routed by 
 static constexpr uint32_t kLdsDistCap = 24576; // u16 distances kept in LDS per query (48 KiB)
 
 using GroupedKernel = void (*)(IndexDev, const float *, const uint32_t *, uint32_t, const uint32_t *, const uint4 *,
-                               const uint32_t *, float *, uint32_t);
+                               const uint32_t *, float *, uint32_t, const float *);
 
 template <int NBLK>
 static GroupedKernel grouped_kernel_metric(uint32_t metric) {
@@ -640,7 +641,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     size_t o_pi = carve(qc * pl.probes * 4), o_pp = carve(qc * pl.probes * 4), o_ps = carve(qc * pl.probes * 4);
     size_t o_sf = carve(qc * 4), o_gc = carve(gw * 4), o_gp = carve(gw * 4), o_gi = carve(gw * 4), o_gf = carve(gw * 4);
     size_t o_git = carve((qc * pl.probes / kGroupPairs + gw + 1) * 16);
-    size_t o_thr = carve(qc * 8), o_sord = carve(qc * pl.sstride * 8);
+    size_t o_thr = carve(qc * 8), o_sord = carve(qc * pl.sstride * 8), o_qn = carve(qc * 4);
     pl.bytes = off;
     ST_TRY(ix->ws.ensure(pl.bytes));
     char *b = static_cast<char *>(ix->ws.p);
@@ -663,6 +664,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     pl.grp_item = (uint32_t *)(b + o_git);
     pl.thr = (uint32_t *)(b + o_thr);
     pl.sel_ord = (uint64_t *)(b + o_sord);
+    pl.qnorm = (float *)(b + o_qn);
     return CUDDLE_OK;
 }
 
@@ -713,6 +715,12 @@ static cuddle_status launch_quantize(cuddle_index *ix, const Plan &pl, const flo
     return CUDDLE_OK;
 }
 
+// Cosine: the query-side norms, once per batch instead of once per (query, stored vector).
+static void launch_query_norms(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, hipStream_t s) {
+    if (ix->dev.metric != CUDDLE_METRIC_COSINE) return;
+    hipLaunchKernelGGL(query_norm_kernel, dim3((nq * 4 + 255) / 256), dim3(256), 0, s, dq, nq, ix->dev.dim, pl.qnorm);
+}
+
 // All tree levels (hierarchical.rs:349-423). Leaves end up in pl.leaves / pl.lcount.
 // A level whose frontier is the same for every query (all earlier levels kept all their nodes)
 // and wider than probes goes through the MFMA contraction + exact refinement; every other level
@@ -725,6 +733,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
     // breadth-first order (true while all earlier levels kept all their nodes, search() only:
     // search_with_stats re-orders every level).
     bool shared = !stats;
+    launch_query_norms(ix, pl, dq, nq, s);
     hipLaunchKernelGGL(route_init_kernel, dim3((v.n_roots + 255) / 256, nq), dim3(256), 0, s, v.roots, v.n_roots,
                        pl.frontier[0], pl.fstride, pl.fcount[0], pl.lcount, nq, shared ? 0u : 1u);
     int cur = 0;
@@ -759,7 +768,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             const size_t glds = 2 * (size_t)kGroupNQ * ((v.dim + 3) & ~3u) * sizeof(float);
             auto gk = grouped_kernel_for(v.dim, v.metric);
             hipLaunchKernelGGL(gk, dim3(items), dim3(256), glds, s, v, dq, ix->lvl[l - 1].nodes, wprev, pl.grp_ioff,
-                               reinterpret_cast<const uint4 *>(pl.grp_item), pl.pair_sorted, pl.fdist, pl.fstride);
+                               reinterpret_cast<const uint4 *>(pl.grp_item), pl.pair_sorted, pl.fdist, pl.fstride, pl.qnorm);
             only = pl.small_flag; // queries with small frontiers: the exact kernel below, in their own arithmetic
         }
         // Will the next level evaluate per-query frontiers wider than probes? Then this level's
@@ -806,7 +815,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 hipLaunchKernelGGL(route_prefilter_kernel, dim3(nq), dim3(256), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,
                                    pl.kc_cap, pl.rc_max);
             hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
-                               g.nodes, pl.rc_pos, pl.kc_cap, kc, pl.rc_dist);
+                               g.nodes, pl.rc_pos, pl.kc_cap, kc, pl.rc_dist, pl.qnorm);
             hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(kc), pl.probes), s,
                                v, g.nodes, n, pl.rc_pos, pl.rc_dist, pl.kc_cap, kc, pl.rc_max, pl.qsq, g.max_sqn, pl.probes,
                                pl.frontier[cur ^ 1], pl.fstride, pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,
@@ -815,7 +824,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         }
         if (!keep_all) // after the MFMA or grouped path only the (rare) flagged queries do work here: few blocks per query
             hipLaunchKernelGGL(route_dist_kernel, dim3((use_gemm || grouped) ? 4 : std::min<uint32_t>((bound + 63) / 64, 64), nq), dim3(256), v.dim * sizeof(float), s, v, dq,
-                               pl.frontier[cur], pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, only);
+                               pl.frontier[cur], pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, only, pl.qnorm);
         const uint32_t *sel_only = grouped ? nullptr : only; // after the grouped path every query still selects here
 #define CUDDLE_SELECT_REG(T, K)                                                                                              \
     hipLaunchKernelGGL((route_select_reg_kernel<T, K>), dim3(nq), dim3(T), route_select_reg_lds_bytes(scap), s, v, pl.frontier[cur], \
@@ -883,8 +892,9 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
 
 static cuddle_status launch_rerank(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, hipStream_t s) {
     const IndexDev &v = ix->dev;
+    launch_query_norms(ix, pl, dq, nq, s);
     hipLaunchKernelGGL(rerank_kernel, dim3((pl.sstride + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
-                       pl.sel_pos, pl.sstride, pl.sel_count, pl.sel_dist);
+                       pl.sel_pos, pl.sstride, pl.sel_count, pl.sel_dist, pl.qnorm);
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
 }

@@ -51,7 +51,7 @@ struct IndexDev {
 
 // Debug builds (-DCUDDLE_STAMP_KERNEL=<id>) record the 100 MHz clock at up to 8 points of every
 // block of ONE kernel (1 Hamming scan, 2 grouped routing distances, 3 register selection,
-// 4 routing finish, 5 register prefilter); cuddle_debug_stamps() reads them back.
+// 4 routing finish, 5 register prefilter, 6 RaBitQ scan); cuddle_debug_stamps() reads them back.
 #ifdef CUDDLE_STAMP_KERNEL
 constexpr uint32_t kStampBlocks = 16384;
 __device__ uint64_t g_dbg_stamps[kStampBlocks * 8];
@@ -72,6 +72,12 @@ __device__ __forceinline__ uint32_t f32_key(float d) {
     if ((b << 1) == 0u) b = 0u;
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
+
+// Pointers known to address LDS (a generic pointer makes the compiler issue flat loads/stores).
+typedef __attribute__((address_space(3))) float LdsF32;
+typedef __attribute__((address_space(3))) uint32_t LdsU32;
+typedef __attribute__((address_space(3))) uint16_t LdsU16;
+typedef __attribute__((address_space(3))) uint8_t LdsU8;
 
 __device__ __forceinline__ uint64_t lanemask_lt() {
     return (1ull << (threadIdx.x & 63)) - 1ull;
@@ -256,13 +262,13 @@ __device__ __forceinline__ void ordered_threshold_compact(uint32_t C, uint32_t T
 // (H = the top bit of every field, L = ~H; neither the sum nor the difference crosses a field).
 // When T + 1 > 2^(B-1) the fields are compared one by one instead.
 // wtmp needs 2 * (blockDim.x / 64) u32. All threads call; contains two barriers.
-template <class DistT, class EmitFn>
-__device__ __forceinline__ void chunked_threshold_select(const DistT *dist, uint32_t C, uint32_t T, uint32_t budget,
+// WordPtr: pointer to the keys seen as u32 words, in the address space they live in.
+template <class DistT, class WordPtr, class EmitFn>
+__device__ __forceinline__ void chunked_threshold_select(WordPtr words, uint32_t C, uint32_t T, uint32_t budget,
                                                          EmitFn emit, uint32_t *wtmp) {
     constexpr uint32_t EPW = 4 / sizeof(DistT), BITS = 8 * sizeof(DistT), MASK = (1u << BITS) - 1;
     constexpr uint32_t H = BITS == 8 ? 0x80808080u : 0x80008000u, L = ~H, ONES = BITS == 8 ? 0x01010101u : 0x00010001u;
     const uint32_t nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t *words = reinterpret_cast<const uint32_t *>(dist);
     const uint32_t nwords = (C + EPW - 1) / EPW;
     const uint32_t mw = (((nwords + nw - 1) / nw + 63) / 64) | 1u; // words per lane, odd
     const uint32_t wb = min((w * 64 + lane) * mw, nwords), we = min(wb + mw, nwords);
@@ -549,6 +555,50 @@ __device__ __forceinline__ void distance_group4_multi(const float *qs, uint32_t 
     }
 }
 
+// dot(a, b) and dot(b, b) of neon16_group4<false> in ONE pass over b: each sum keeps its own
+// accumulators and its own order, so both equal the separately computed values.
+__device__ __forceinline__ void neon16_group4_dot2(const float *a, const float *b, uint32_t n, uint32_t sub, bool vec,
+                                                   float &ab, float &bb) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acb = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t nblk = n >> 4;
+    const float *pa = a + 4 * sub, *pb = b + 4 * sub;
+#pragma unroll 4
+    for (uint32_t t = 0; t < nblk; ++t) {
+        const float4 x = ld4(pa + 16 * t, vec), y = ld4(pb + 16 * t, vec);
+        acc.x = __builtin_fmaf(x.x, y.x, acc.x);
+        acc.y = __builtin_fmaf(x.y, y.y, acc.y);
+        acc.z = __builtin_fmaf(x.z, y.z, acc.z);
+        acc.w = __builtin_fmaf(x.w, y.w, acc.w);
+        acb.x = __builtin_fmaf(y.x, y.x, acb.x);
+        acb.y = __builtin_fmaf(y.y, y.y, acb.y);
+        acb.z = __builtin_fmaf(y.z, y.z, acb.z);
+        acb.w = __builtin_fmaf(y.w, y.w, acb.w);
+    }
+    ab = neon_tail<false>(group4_reduce(acc), a, b, nblk << 4, n);
+    bb = neon_tail<false>(group4_reduce(acb), b, b, nblk << 4, n);
+}
+
+// distance() by a 4-lane group when the query-side norm na = sqrtf(dot(a, a)) is already known
+// (it is the same for every stored vector the query meets): cosine reads b once instead of twice
+// and skips the query's own sum. Same value as distance_group4.
+__device__ __forceinline__ float distance_group4_qn(const float *a, const float *b, uint32_t n, uint32_t metric,
+                                                    uint32_t sub, bool vec, float na) {
+    if (metric == kMetricL2) return neon16_group4<true>(a, b, n, sub, vec);
+    if (metric == kMetricDot) return -neon16_group4<false>(a, b, n, sub, vec);
+    float ab, bb;
+    neon16_group4_dot2(a, b, n, sub, vec, ab, bb);
+    return 1.0f - (ab / (na * sqrtf(bb)));
+}
+
+// qnorm[q] = sqrtf(dot(q, q)) in the arithmetic of distance(): one 4-lane group per query.
+__global__ void query_norm_kernel(const float *queries, uint32_t nq, uint32_t dim, float *qnorm) {
+    const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, sub = threadIdx.x & 3;
+    const bool act = g < nq;
+    const float *q = queries + (uint64_t)(act ? g : 0) * dim;
+    const float s = neon16_group4<false>(q, q, dim, sub, (dim & 3) == 0);
+    if (act && sub == 0) qnorm[g] = sqrtf(s);
+}
+
 __device__ __forceinline__ float distance_serial(const float *a, const float *b, uint32_t n, uint32_t metric) {
     if (metric == kMetricL2) return neon16_serial<true>(a, b, n);
     float dot = neon16_serial<false>(a, b, n);
@@ -782,8 +832,9 @@ __device__ __forceinline__ uint32_t scan_slot_of(const uint32_t *lscan, uint32_t
 // and issues all of their 128-bit loads (U * PAIRS per lane, every one a fully coalesced
 // wave-wide read of consecutive 16-byte slots) before the first XOR/popcount, so that one wave
 // keeps U * PAIRS KiB in flight. Distances are stored by scan position.
-template <int PAIRS, bool TAIL, int U, class DistT>
-__device__ __forceinline__ void scan_tiles(const IndexDev &ix, const ScanLds &s, uint32_t ntiles, DistT *dist) {
+// DistPtr: DistT * in the address space the distances live in (LDS or the global spill buffer).
+template <int PAIRS, bool TAIL, int U, class DistT, class DistPtr>
+__device__ __forceinline__ void scan_tiles(const IndexDev &ix, const ScanLds &s, uint32_t ntiles, DistPtr dist) {
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if (PAIRS == 1 && !TAIL) {
         // two-word codes: one 16-byte slot per vector, addressed through the per-tile tables alone
@@ -927,11 +978,14 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
     // histogram mode (ghist != null, leaf-sharded search): distances go to the spill buffer and the
     // kernel ends after phase 1 with the query's local histogram; the selection follows once the
     // histograms of all shards are summed (cuddle_shard.hpp)
-    DistT *dist = (C <= dist_cap && !ghist) ? reinterpret_cast<DistT *>(s.dist)
-                                   : reinterpret_cast<DistT *>(gdist_v) + (uint64_t)q * gdist_stride;
+    // The rest of the kernel, once for each address space the distances can live in: a pointer
+    // that may be either makes every access a flat instruction.
+    typedef __attribute__((address_space(3))) DistT LdsDist;
+    typedef const __attribute__((address_space(3))) uint32_t LdsWord;
+    auto body = [&](auto dist, auto dist_words) {
     // phase 1
     if (PAIRS > 0) {
-        scan_tiles<PAIRS, TAIL, U>(ix, s, ntiles, dist);
+        scan_tiles<PAIRS, TAIL, U, DistT>(ix, s, ntiles, dist);
     } else {
         for (uint32_t t = w; t < ntiles; t += nw) {
             const uint32_t tile = s.tiles[t], sl = tile >> 12, i = ((tile & 4095u) << 6) + lane;
@@ -987,8 +1041,8 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
     const uint32_t nsel = min(min(C, rerank_k), sel_stride);
     uint32_t *stg = s.tiles;
     const bool stage_lds = nsel <= ((PAIRS == 1 && !TAIL) ? 3u : 2u) * scan_pad4(tcap);
-    chunked_threshold_select(
-        dist, C, T, budget,
+    chunked_threshold_select<DistT>(
+        dist_words, C, T, budget,
         [&](uint32_t i, uint32_t, uint32_t rank) {
             if (rank < nsel) {
                 if (stage_lds) stg[rank] = i; else sp[rank] = i;
@@ -1007,6 +1061,13 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
     }
     CUDDLE_STAMP(1, 4);
     if (tid == 0) sel_count[q] = nsel;
+    }; // body
+    if (C <= dist_cap && !ghist) {
+        body((LdsDist *)s.dist, (LdsWord *)s.dist);
+    } else {
+        DistT *gd = reinterpret_cast<DistT *>(gdist_v) + (uint64_t)q * gdist_stride;
+        body(gd, reinterpret_cast<const uint32_t *>(gd));
+    }
 }
 
 // collect_leaf_candidates (hierarchical.rs:618-641) written out in full: every candidate's
@@ -1045,7 +1106,7 @@ scan_all_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *lea
 // group streams one candidate row with 128-bit loads (64 contiguous bytes per group and step).
 __global__ void __launch_bounds__(256)
 rerank_kernel(IndexDev ix, const float *queries, const uint32_t *sel_pos, uint32_t sel_stride,
-              const uint32_t *sel_count, float *sel_dist) {
+              const uint32_t *sel_count, float *sel_dist, const float *qnorm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);
     const uint32_t q = blockIdx.y;
@@ -1059,7 +1120,8 @@ rerank_kernel(IndexDev ix, const float *queries, const uint32_t *sel_pos, uint32
     const bool act = j < n;
     const uint32_t pos = sel_pos[(uint64_t)q * sel_stride + (act ? j : 0)];
     const bool vec = (D & 3) == 0;
-    float d = distance_group4(qs, ix.vectors + (uint64_t)pos * D, D, ix.metric, sub, vec);
+    float d = distance_group4_qn(qs, ix.vectors + (uint64_t)pos * D, D, ix.metric, sub, vec,
+                                 ix.metric == kMetricCosine ? qnorm[q] : 0.f);
     if (act && sub == 0) sel_dist[(uint64_t)q * sel_stride + j] = d;
 }
 

@@ -65,24 +65,36 @@ rabitq_query_prep_kernel(const float *queries, const float *rot, uint32_t nq, ui
 // estimate_distance_fast (rabitq.rs:335-363) for vector i of a leaf of n vectors whose codes are
 // stored word-major ([w][n] u32): ip = sum_i (bit_i ? +rq_i : -rq_i) sequentially
 // (compute_inner_product_fast, :298-321), est = (2 - 2 ip / ip_oo) * norm * qnorm.
+// The query side arrives split into magnitudes arq[i] = |rq_i| and sign words qsign (bit i of word
+// i / 32 = sign bit of rq_i): the sign of term i is sign(rq_i) ^ ~bit_i, i.e. bit i of
+// qsign ^ ~code, OR-ed into the magnitude (one and-or instruction) — the same bit pattern as
+// flipping rq_i's sign where the code bit is 0, for one operation less per element.
 __device__ __forceinline__ float rabitq_estimate(const uint32_t *codes, uint32_t n, uint32_t i, uint32_t dim,
-                                                 uint32_t words32, const float *rq, float qnorm, float norm, float ipoo) {
+                                                 uint32_t words32, const float *arq, const uint32_t *qsign, float qnorm,
+                                                 float norm, float ipoo) {
     if (qnorm < 1e-10f) return norm * norm; // rabitq.rs:408-413 (whole batch) and :342-349
     if (norm < 1e-10f) return qnorm * qnorm;
+    // the query side lives in LDS: say so, or the reads are issued as (slower) flat loads
+    const LdsF32 *la = (const LdsF32 *)arq;
+    const LdsU32 *ls = (const LdsU32 *)qsign;
     float sum = 0.f;
-    for (uint32_t w = 0; w < words32; ++w) {
-        const uint32_t inv = ~codes[(uint64_t)w * n + i];
-        const uint32_t lim = min(32u, dim - 32u * w);
-        if (lim == 32) {
+    for (uint32_t w0 = 0; w0 < words32; w0 += 8) { // eight code words in flight per lane
+        uint32_t cw[8];
 #pragma unroll
-            for (uint32_t b = 0; b < 32; ++b) {
-                const uint32_t m = (inv << (31 - b)) & 0x80000000u; // sign flip where the bit is 0
-                sum += __uint_as_float(__float_as_uint(rq[32 * w + b]) ^ m);
-            }
-        } else {
-            for (uint32_t b = 0; b < lim; ++b) {
-                const uint32_t m = (inv << (31 - b)) & 0x80000000u;
-                sum += __uint_as_float(__float_as_uint(rq[32 * w + b]) ^ m);
+        for (uint32_t u = 0; u < 8; ++u) cw[u] = w0 + u < words32 ? codes[(uint64_t)(w0 + u) * n + i] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t w = w0 + u;
+            if (w >= words32) break;
+            const uint32_t sg = ls[w] ^ ~cw[u];
+            const uint32_t lim = min(32u, dim - 32u * w);
+            if (lim == 32) {
+#pragma unroll
+                for (uint32_t b = 0; b < 32; ++b)
+                    sum += __uint_as_float(((sg << (31 - b)) & 0x80000000u) | __float_as_uint(la[32 * w + b])); // v_and_or_b32
+            } else {
+                for (uint32_t b = 0; b < lim; ++b)
+                    sum += __uint_as_float(((sg << (31 - b)) & 0x80000000u) | __float_as_uint(la[32 * w + b]));
             }
         }
     }
@@ -91,14 +103,32 @@ __device__ __forceinline__ float rabitq_estimate(const uint32_t *codes, uint32_t
     return dn * norm * qnorm;
 }
 
+// Stages one query's rotated vector in LDS as magnitudes (arq[dim]) and sign words (qsign); all
+// zeros when the query norm is below the reference's cut-off (the estimates then ignore it).
+// All threads of the block call; the caller synchronises before reading.
+__device__ __forceinline__ void rabitq_stage_query(const float *rq, uint32_t dim, float qnorm, float *arq, uint32_t *qsign) {
+    const uint32_t lane = threadIdx.x & 63, dpad = (dim + 63) & ~63u;
+    for (uint32_t i = threadIdx.x; i < dpad; i += blockDim.x) { // whole waves: the ballot covers 64 consecutive elements
+        const uint32_t bits = (i < dim && qnorm >= 1e-10f) ? __float_as_uint(rq[i]) : 0u;
+        if (i < dim) arq[i] = __uint_as_float(bits & 0x7FFFFFFFu);
+        const uint64_t sb = __ballot((bits >> 31) != 0);
+        if (lane == 0) {
+            qsign[i >> 5] = (uint32_t)sb;
+            qsign[(i >> 5) + 1] = (uint32_t)(sb >> 32);
+        }
+    }
+}
+
 inline size_t rabitq_scan_lds_bytes(uint32_t dim, uint32_t lcap, uint32_t tcap, uint32_t dist_cap) {
-    return scan_lds_bytes(0, 0, lcap, tcap, 0) + 256 * 4 + (size_t)((dim + 3) & ~3u) * 4 + (size_t)dist_cap * 4 + 64;
+    return scan_lds_bytes(0, 0, lcap, tcap, 0) + 256 * 4 + (size_t)((dim + 3) & ~3u) * 4 + (size_t)((dim + 63) / 64) * 8 +
+           (size_t)dist_cap * 4 + 64;
 }
 
 struct RabitqLds {
     ScanLds s;
     uint32_t *rhist; // [256] radix-select histogram
-    float *rq;       // [dim]
+    float *rq;       // [dim]  |rotated query|
+    uint32_t *qsign; // [2 * ceil(dim / 64)] sign bits of the rotated query
     float *est;      // [dist_cap]
 };
 
@@ -109,6 +139,8 @@ __device__ __forceinline__ RabitqLds rabitq_lds_carve(unsigned char *smem, uint3
     p = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
     r.rhist = p; p += 256;
     r.rq = reinterpret_cast<float *>(p); p += (dim + 3) & ~3u;
+    r.qsign = p; p += 2 * ((dim + 63) / 64);
+    p = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
     r.est = reinterpret_cast<float *>(p);
     return r;
 }
@@ -132,7 +164,8 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
     const ScanLds &s = r.s;
     const uint32_t nl = min(lcount[q], lcap);
     const float qnorm = qnorm_all[q];
-    for (uint32_t i = tid; i < D; i += blockDim.x) r.rq[i] = qnorm >= 1e-10f ? rq_all[(uint64_t)q * D + i] : 0.f;
+    CUDDLE_STAMP(6, 0);
+    rabitq_stage_query(rq_all + (uint64_t)q * D, D, qnorm, r.rq, r.qsign);
     uint32_t ntiles = 0;
     const uint32_t C = scan_load_leaves(ix, s, leaves + (uint64_t)q * lstride, nl, tcap, &ntiles);
     if (tid == 0) cand_count[q] = C;
@@ -142,22 +175,25 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
     }
     const bool use_lds = C <= dist_cap;
     float *ge = gest + (uint64_t)q * gest_stride;
+    CUDDLE_STAMP(6, 1);
     for (uint32_t t = w; t < ntiles; t += nw) {
         const uint32_t tile = s.tiles[t], sl = tile >> 12, i = ((tile & 4095u) << 6) + lane;
         const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base;
         if (i < n) {
             const uint32_t pos = s.lbeg[sl] + i;
-            float e = rabitq_estimate(ix.rq_codes + (uint64_t)s.lbeg[sl] * W32, n, i, D, W32, r.rq, qnorm, ix.rq_norm[pos],
-                                      ix.rq_ipoo[pos]);
+            float e = rabitq_estimate(ix.rq_codes + (uint64_t)s.lbeg[sl] * W32, n, i, D, W32, r.rq, r.qsign, qnorm,
+                                      ix.rq_norm[pos], ix.rq_ipoo[pos]);
             if (use_lds) r.est[base + i] = e; else ge[base + i] = e;
         }
     }
     __syncthreads();
+    CUDDLE_STAMP(6, 2);
     auto key = [&](uint32_t i) -> uint32_t { return f32_key(use_lds ? r.est[i] : ge[i]); };
     auto key2 = [&](uint32_t i, uint32_t &) -> uint32_t { return key(i); };
     uint32_t T = 0xFFFFFFFFu, budget = 0;
     bool all = C <= rerank_k;
     if (!all) T = block_radix_select(C, rerank_k, key, r.rhist, s.misc, budget);
+    CUDDLE_STAMP(6, 3);
     uint32_t *sp = sel_pos + (uint64_t)q * sel_stride, *sk = sel_key + (uint64_t)q * sel_stride;
     auto emit = [&](uint32_t i, uint32_t, uint32_t, uint32_t rank) {
         if (rank < sel_stride) {
@@ -173,6 +209,7 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
     } else {
         ordered_threshold_compact_aux(C, T, budget, key2, emit, s.wtmp);
     }
+    CUDDLE_STAMP(6, 4);
     if (tid == 0) sel_count[q] = min(min(C, rerank_k), sel_stride);
 }
 
@@ -188,15 +225,15 @@ scan_all_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_all,
     const ScanLds &s = r.s;
     const uint32_t nl = min(lcount[q], lcap);
     const float qnorm = qnorm_all[q];
-    for (uint32_t i = tid; i < D; i += blockDim.x) r.rq[i] = qnorm >= 1e-10f ? rq_all[(uint64_t)q * D + i] : 0.f;
+    rabitq_stage_query(rq_all + (uint64_t)q * D, D, qnorm, r.rq, r.qsign);
     const uint32_t C = scan_load_leaves(ix, s, leaves + (uint64_t)q * lstride, nl, 0, nullptr);
     if (tid == 0) cand_count[q] = C;
     for (uint32_t sl = w; sl < nl; sl += nw) {
         const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base;
         for (uint32_t i = lane; i < n; i += 64) {
             const uint32_t pos = s.lbeg[sl] + i;
-            float e = rabitq_estimate(ix.rq_codes + (uint64_t)s.lbeg[sl] * W32, n, i, D, W32, r.rq, qnorm, ix.rq_norm[pos],
-                                      ix.rq_ipoo[pos]);
+            float e = rabitq_estimate(ix.rq_codes + (uint64_t)s.lbeg[sl] * W32, n, i, D, W32, r.rq, r.qsign, qnorm,
+                                      ix.rq_norm[pos], ix.rq_ipoo[pos]);
             if (base + i < cand_stride) {
                 out_pos[(uint64_t)q * cand_stride + base + i] = pos;
                 out_key[(uint64_t)q * cand_stride + base + i] = __float_as_uint(e);

@@ -247,7 +247,7 @@ __global__ void route_init_kernel(const uint32_t *roots, uint32_t n_roots, uint3
 __global__ void __launch_bounds__(256)
 route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, uint32_t fstride,
                   const uint32_t *fcount, const uint32_t *shared_fr, uint32_t shared_n, float *fdist, uint32_t probes,
-                  uint32_t stats_variant, const uint32_t *only_flag) {
+                  uint32_t stats_variant, const uint32_t *only_flag, const float *qnorm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);
     const uint32_t q = blockIdx.y;
@@ -276,7 +276,8 @@ route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, u
         const uint32_t j = j0 + (threadIdx.x >> 2);
         const bool act = j < n;
         const uint32_t node = fr[act ? j : 0];
-        float d = distance_group4(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, vec);
+        float d = distance_group4_qn(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, vec,
+                                     ix.metric == kMetricCosine ? qnorm[q] : 0.f);
         if (act && sub == 0) fd[j] = d;
     }
 }
@@ -516,7 +517,7 @@ template <int NBLK, uint32_t METRIC>
 __global__ void __launch_bounds__(256, (NBLK > 8 ? 2 : 4) - (METRIC == kMetricCosine ? 1 : 0)) // waves per SIMD the registers must allow
 route_dist_grouped_kernel(IndexDev ix, const float *queries, const uint32_t *level_nodes, uint32_t n_parents,
                           const uint32_t *ioff, const uint4 *items, const uint32_t *sorted, float *fdist,
-                          uint32_t fstride) {
+                          uint32_t fstride, const float *qnorm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qbuf = reinterpret_cast<float *>(smem);
     __shared__ uint32_t pk[kGroupPairs];
@@ -655,7 +656,7 @@ route_dist_grouped_kernel(IndexDev ix, const float *queries, const uint32_t *lev
                         if (METRIC == kMetricDot) {
                             d = -dot;
                         } else {
-                            const float na = sqrtf(neon16_group4<false>(qa, qa, D, sub, vec));
+                            const float na = qnorm[pk[min(t0 + jh + j, np - 1)] >> kPairOffBits]; // sqrtf(dot(q, q)), once per query
                             d = 1.0f - (dot / (na * nb));
                         }
                     }
@@ -927,7 +928,7 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
 // grid = (ceil(kc/64), nq), block 256: one 4-lane group per (query, candidate).
 __global__ void __launch_bounds__(256)
 route_refine_kernel(IndexDev ix, const float *queries, const uint32_t *level_nodes, const uint32_t *cand_pos,
-                    uint32_t cstride, uint32_t kc, float *cand_dist) {
+                    uint32_t cstride, uint32_t kc, float *cand_dist, const float *qnorm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);
     const uint32_t q = blockIdx.y, D = ix.dim;
@@ -937,7 +938,8 @@ route_refine_kernel(IndexDev ix, const float *queries, const uint32_t *level_nod
     const uint32_t j = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
     const bool act = j < kc;
     const uint32_t node = level_nodes[cand_pos[(uint64_t)q * cstride + (act ? j : 0)]];
-    float d = distance_group4(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, (D & 3) == 0);
+    float d = distance_group4_qn(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, (D & 3) == 0,
+                                 ix.metric == kMetricCosine ? qnorm[q] : 0.f);
     if (act && sub == 0) cand_dist[(uint64_t)q * cstride + j] = d;
 }
 

@@ -33,7 +33,12 @@ class DeviceTreeIndex:
     centroids: torch.Tensor     # device f32 [n_nodes, dim]
     ids: torch.Tensor           # device i64 [N]
     vectors: torch.Tensor       # device f32 [N, dim]
-    codes: torch.Tensor         # device i64 [N, W]
+    codes: torch.Tensor = None  # device i64 [N, W]           (binary codes)
+    code_kind: int = _ffi.CODE_BINARY
+    rot_t: torch.Tensor = None      # device f32 [dim, dim]   (RaBitQ: rotation_matrix_t)
+    rq_codes: torch.Tensor = None   # device i32 [N, ceil(dim/32)] (bit pattern of u32 words)
+    rq_norm: torch.Tensor = None    # device f32 [N]
+    rq_ipoo: torch.Tensor = None    # device f32 [N]
 
     @property
     def n_vectors(self) -> int:
@@ -42,7 +47,7 @@ class DeviceTreeIndex:
     def desc(self) -> _ffi.IndexDesc:
         d = _ffi.IndexDesc()
         d.abi_version = _ffi.ABI_VERSION
-        d.dim, d.metric, d.code_kind = self.dim, self.metric, _ffi.CODE_BINARY
+        d.dim, d.metric, d.code_kind = self.dim, self.metric, self.code_kind
         d.n_nodes, d.n_roots, d.n_vectors = int(self.centroids.shape[0]), int(self.roots.shape[0]), self.n_vectors
         d.child_offsets = C.c_void_p(self.child_offsets.ctypes.data)
         d.children = C.c_void_p(self.children.ctypes.data)
@@ -51,7 +56,13 @@ class DeviceTreeIndex:
         d.centroids = C.c_void_p(self.centroids.data_ptr())
         d.ids = C.c_void_p(self.ids.data_ptr())
         d.vectors = C.c_void_p(self.vectors.data_ptr())
-        d.codes = C.c_void_p(self.codes.data_ptr())
+        if self.code_kind == _ffi.CODE_BINARY:
+            d.codes = C.c_void_p(self.codes.data_ptr())
+        else:
+            d.rabitq_rot_t = C.c_void_p(self.rot_t.data_ptr())
+            d.rabitq_codes = C.c_void_p(self.rq_codes.data_ptr())
+            d.rabitq_norm = C.c_void_p(self.rq_norm.data_ptr())
+            d.rabitq_ip_oo = C.c_void_p(self.rq_ipoo.data_ptr())
         d.threshold = self.threshold
         d.flags = _ffi.DESC_DEVICE_ARRAYS | _ffi.DESC_ADOPT_VECTORS
         return d
@@ -64,11 +75,15 @@ class DeviceTreeIndex:
 
     def to_flat(self) -> FlatIndex:
         """Host copy (small cases: lets the oracle check the same index)."""
-        return FlatIndex(dim=self.dim, metric=self.metric, code_kind=_ffi.CODE_BINARY,
+        rq = {}
+        if self.code_kind == _ffi.CODE_RABITQ:
+            rq = dict(rabitq_rot_t=self.rot_t.cpu().numpy(), rabitq_codes=self.rq_codes.cpu().numpy().view(np.uint32),
+                      rabitq_norm=self.rq_norm.cpu().numpy(), rabitq_ip_oo=self.rq_ipoo.cpu().numpy())
+        return FlatIndex(dim=self.dim, metric=self.metric, code_kind=self.code_kind,
                          centroids=self.centroids.cpu().numpy(), child_offsets=self.child_offsets, children=self.children,
                          roots=self.roots, vec_offsets=self.vec_offsets, ids=self.ids.cpu().numpy().astype(np.uint64),
                          vectors=self.vectors.cpu().numpy(), threshold=self.threshold,
-                         codes=self.codes.cpu().numpy().view(np.uint64)).normalised()
+                         codes=None if self.codes is None else self.codes.cpu().numpy().view(np.uint64), **rq).normalised()
 
 
 def _pack_codes(x: torch.Tensor, threshold: float) -> torch.Tensor:
@@ -81,9 +96,34 @@ def _pack_codes(x: torch.Tensor, threshold: float) -> torch.Tensor:
     return halves[..., 0] | (halves[..., 1] << 32)
 
 
+def _rabitq_encode_device(vectors: torch.Tensor, rot_t: torch.Tensor, chunk: int = 1 << 18):
+    """RaBitQQuantizer::quantize (/root/reference/src/quantization/rabitq.rs:114-171) for a matrix
+    on the device, the formulation of builder.rabitq_encode: norm, sign code of the rotated unit
+    vector (bit i of u32 word i // 32), sum |rotated| as <o_bar, o>. Zero vectors: code 0, norm 0, 1.0."""
+    n, d = vectors.shape
+    words = (d + 31) // 32
+    codes = torch.empty((n, words), dtype=torch.int32, device=vectors.device)
+    norms = torch.empty(n, dtype=torch.float32, device=vectors.device)
+    ipoo = torch.empty(n, dtype=torch.float32, device=vectors.device)
+    sh = torch.arange(32, device=vectors.device, dtype=torch.int64)
+    for a in range(0, n, chunk):
+        v = vectors[a:a + chunk]
+        nr = v.norm(dim=1)
+        zero = nr < 1e-10
+        rot = (v / nr.clamp_min(1e-30)[:, None]) @ rot_t.t()
+        bits = torch.zeros((v.shape[0], words * 32), dtype=torch.int64, device=v.device)
+        bits[:, :d] = (rot >= 0).to(torch.int64)
+        bits[zero] = 0
+        w = (bits.view(-1, words, 32) << sh).sum(-1)            # 0 .. 2^32 - 1
+        codes[a:a + chunk] = torch.where(w >= (1 << 31), w - (1 << 32), w).to(torch.int32)
+        norms[a:a + chunk] = torch.where(zero, torch.zeros_like(nr), nr)
+        ipoo[a:a + chunk] = torch.where(zero, torch.ones_like(nr), rot.abs().sum(1))
+    return codes, norms, ipoo
+
+
 def build_tree_index_on_device(dim: int, fanout: int, levels: int, leaf_size: int, device, seed: int = 0,
                                sigmas=(0.35, 0.22, 0.12), metric: int = _ffi.METRIC_L2, style: str = "sift",
-                               n_queries: int = 0, chunk_leaves: int = 8192):
+                               n_queries: int = 0, chunk_leaves: int = 8192, code_kind: int = _ffi.CODE_BINARY):
     """Returns (DeviceTreeIndex, queries [n_queries, dim]). N = fanout**levels * leaf_size vectors.
     sigmas: spread of each level's centres around its parent, last entry = spread of the points
     around their leaf centre. style "sift": values mapped to non-negative integers in the u8 range."""
@@ -118,10 +158,17 @@ def build_tree_index_on_device(dim: int, fanout: int, levels: int, leaf_size: in
         total += x.double().sum()
         vectors[a * leaf_size:b * leaf_size] = x.reshape(-1, dim)
     threshold = float((total / (n_vec * dim)).item())
-    codes = torch.empty((n_vec, (dim + 63) // 64), dtype=torch.int64, device=device)
-    step = 1 << 20
-    for a in range(0, n_vec, step):
-        codes[a:a + step] = _pack_codes(vectors[a:a + step], threshold)
+    codes, rq = None, {}
+    if code_kind == _ffi.CODE_BINARY:
+        codes = torch.empty((n_vec, (dim + 63) // 64), dtype=torch.int64, device=device)
+        step = 1 << 20
+        for a in range(0, n_vec, step):
+            codes[a:a + step] = _pack_codes(vectors[a:a + step], threshold)
+    else:
+        from .builder import make_rotation
+        rot_t = torch.from_numpy(make_rotation(dim, seed + 17)).to(device)
+        rc, rn, ri = _rabitq_encode_device(vectors, rot_t)
+        rq = dict(rot_t=rot_t, rq_codes=rc, rq_norm=rn, rq_ipoo=ri)
     # centroids bottom-up
     cents = [None] * levels
     cents[-1] = leaf_cent
@@ -145,5 +192,6 @@ def build_tree_index_on_device(dim: int, fanout: int, levels: int, leaf_size: in
         leaf = torch.randint(0, n_leaves, (n_queries,), generator=g, device=device)
         queries = finish(centres[-1][leaf] + sig_pts * torch.randn((n_queries, dim), generator=g, device=device))
     idx = DeviceTreeIndex(dim=dim, metric=metric, threshold=threshold, child_offsets=child_offsets, children=children,
-                          roots=roots, vec_offsets=vec_offsets, centroids=centroids, ids=ids, vectors=vectors, codes=codes)
+                          roots=roots, vec_offsets=vec_offsets, centroids=centroids, ids=ids, vectors=vectors, codes=codes,
+                          code_kind=code_kind, **rq)
     return idx, queries.contiguous()
