@@ -796,12 +796,18 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             const uint32_t gy = (nq + kGemmBM - 1) / kGemmBM, gx2 = (n + 127) / 128, gx1 = (n + 63) / 64;
             const uint32_t cus = ix->n_cus;
             const uint32_t cost2 = 2 * ((gx2 * gy + cus - 1) / cus), cost1 = (gx1 * gy + cus - 1) / cus;
+            // XCD row groups: as few as keep an XCD's share of A within half of its 4 MiB L2
+            uint32_t rg = 1;
+            while (rg < 8 && (uint64_t)nq * v.dim * 4 / rg > (2u << 20) && gy >= 2 * rg) rg *= 2;
+            const uint32_t rows_per = (gy + rg - 1) / rg, pgroups = 8 / rg;
             if (cost1 < cost2)
-                hipLaunchKernelGGL(route_gemm_kernel<1>, dim3(8 * ((gx1 + 7) / 8) * gy), dim3(256), route_gemm_lds_bytes(1), s,
-                                   pl.qcent, pl.qsq, g.table, g.sqn, nq, n, v.dim, v.metric, pl.fdist, pl.fstride, gx1, gy);
+                hipLaunchKernelGGL(route_gemm_kernel<1>, dim3(8 * rows_per * ((gx1 + pgroups - 1) / pgroups)), dim3(256),
+                                   route_gemm_lds_bytes(1), s, pl.qcent, pl.qsq, g.table, g.sqn, nq, n, v.dim, v.metric, pl.fdist,
+                                   pl.fstride, gx1, gy, rg);
             else
-                hipLaunchKernelGGL(route_gemm_kernel<2>, dim3(8 * ((gx2 + 7) / 8) * gy), dim3(256), route_gemm_lds_bytes(2), s,
-                                   pl.qcent, pl.qsq, g.table, g.sqn, nq, n, v.dim, v.metric, pl.fdist, pl.fstride, gx2, gy);
+                hipLaunchKernelGGL(route_gemm_kernel<2>, dim3(8 * rows_per * ((gx2 + pgroups - 1) / pgroups)), dim3(256),
+                                   route_gemm_lds_bytes(2), s, pl.qcent, pl.qsq, g.table, g.sqn, nq, n, v.dim, v.metric, pl.fdist,
+                                   pl.fstride, gx2, gy, rg);
             if (n <= (uint32_t)kPrefKpt * 128)
                 hipLaunchKernelGGL(route_prefilter_reg_kernel<128>, dim3(nq), dim3(128), 0, s, pl.fdist, pl.fstride, n, kc,
                                    pl.rc_pos, pl.kc_cap, pl.rc_max);

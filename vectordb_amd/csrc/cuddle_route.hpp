@@ -738,21 +738,23 @@ inline size_t route_gemm_lds_bytes(int nt) { return (size_t)2 /*parity*/ * (kGem
 // leaves fewer idle CUs in the last round of blocks.
 // LDS image per operand: [k parity h][row][s] with k = 2s + h, so a lane reads its 16 k-values of
 // a K step with four ds_read_b128. Global tiles are prefetched into registers one K step ahead.
-// Blocks are numbered so that the row blocks of one column panel share an XCD (its L2 keeps the
-// panel of B): id % 8 selects the XCD, panels x = 8 * xl + xcd belong to XCD xcd.
-// K must be a multiple of 4. out: [M][ostride].
+// Blocks are numbered for the XCDs' private L2s (block id % 8 = XCD): the 8 XCDs form rg row
+// groups x (8 / rg) panel groups; an XCD works on its row group's tiles of A (kept in its L2: the
+// host picks rg so that they take at most half of it) against its panel group's column panels of
+// B, the row tiles of one panel running together so that the panel is fetched once.
+// K must be a multiple of 4. out: [M][ostride]. grid = 8 * ceil(gy / rg) * ceil(gx / (8 / rg)).
 template <int NT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, NT == 1 ? 5 : 3) // blocks of 4 waves per CU the register allocation must allow
 route_gemm_kernel(const float *A, const float *Asq, const float *B, const float *Bsq, uint32_t M, uint32_t N,
-                  uint32_t K, uint32_t metric, float *out, uint32_t ostride, uint32_t gx, uint32_t gy) {
+                  uint32_t K, uint32_t metric, float *out, uint32_t ostride, uint32_t gx, uint32_t gy, uint32_t rg) {
     constexpr int BN = 64 * NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *As = reinterpret_cast<float *>(smem);            // [2][128][20]
     float *Bs = As + 2 * kGemmBM * kGemmLdsRow;             // [2][BN][20]
     const uint32_t id = blockIdx.x;
-    const uint32_t xcd = id & 7, local = id >> 3;
-    const uint32_t bx = (local / gy) * 8 + xcd, by = local % gy;
-    if (bx >= gx) return;
+    const uint32_t xcd = id & 7, local = id >> 3, pgroups = 8 / rg, rows_per = (gy + rg - 1) / rg;
+    const uint32_t by = (xcd % rg) * rows_per + local % rows_per, bx = (local / rows_per) * pgroups + xcd / rg;
+    if (bx >= gx || by >= gy) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t wr = w >> 1, wc = w & 1, r = lane & 31, h = lane >> 5;
     // global -> register staging: thread covers rows (tid>>3) + 32 i, floats 4 (tid&7) .. +3
