@@ -908,10 +908,21 @@ static cuddle_status launch_rerank(cuddle_index *ix, const Plan &pl, const float
 static cuddle_status launch_topk(cuddle_index *ix, const Plan &pl, uint32_t nq, uint64_t *d_ids, float *d_dist,
                                  uint32_t *d_count, hipStream_t s, uint64_t *d_order = nullptr) {
     const IndexDev &v = ix->dev;
-    size_t lds = (size_t)host_next_pow2(pl.sstride) * 8;
-    hipLaunchKernelGGL(topk_kernel, dim3(nq), dim3(256), lds, s, v, pl.sel_pos, pl.sel_key, pl.sel_dist, pl.sstride,
-                       pl.sel_count, pl.k, v.code_kind == CUDDLE_CODE_RABITQ ? 1u : 0u, d_ids, d_dist, d_count,
-                       d_order ? pl.sel_ord : nullptr, d_order);
+    const uint32_t rk = v.code_kind == CUDDLE_CODE_RABITQ ? 1u : 0u;
+#define CUDDLE_TOPK_WAVE(KPL)                                                                                                 \
+    hipLaunchKernelGGL(topk_wave_kernel<KPL>, dim3(nq), dim3(64), 0, s, v, pl.sel_pos, pl.sel_key, pl.sel_dist,                \
+                       pl.sstride, pl.sel_count, pl.k, rk, d_ids, d_dist, d_count, d_order ? pl.sel_ord : nullptr, d_order, nq)
+    if (pl.k <= 16 && pl.sstride <= 256) {
+        CUDDLE_TOPK_WAVE(4);
+    } else if (pl.k <= 16 && pl.sstride <= 512) {
+        CUDDLE_TOPK_WAVE(8);
+    } else if (pl.k <= 16 && pl.sstride <= 1024) {
+        CUDDLE_TOPK_WAVE(16);
+    } else {
+        size_t lds = (size_t)host_next_pow2(pl.sstride) * 8;
+        hipLaunchKernelGGL(topk_kernel, dim3(nq), dim3(256), lds, s, v, pl.sel_pos, pl.sel_key, pl.sel_dist, pl.sstride,
+                           pl.sel_count, pl.k, rk, d_ids, d_dist, d_count, d_order ? pl.sel_ord : nullptr, d_order);
+    }
     hipLaunchKernelGGL(stats_accum_kernel, dim3(std::min<uint32_t>((nq + 255) / 256, 8)), dim3(256), 0, s, pl.lcount, pl.cand_count,
                        pl.sel_count, nq, ix->d_stats);
     HIP_TRY(hipGetLastError());

@@ -1167,6 +1167,63 @@ topk_kernel(IndexDev ix, const uint32_t *sel_pos, const uint32_t *sel_key, const
     if (tid == 0 && out_count) out_count[q] = nout;
 }
 
+// topk_kernel for k <= 64 and selections of at most 64 * KPL candidates: one WAVE per query (one
+// query per 64 threads of the block), the keys in registers (KPL per lane), k rounds of "smallest
+// key of the wave, its owner retires it". No LDS, no barrier. Same keys, same order.
+template <int KPL>
+__global__ void __launch_bounds__(256)
+topk_wave_kernel(IndexDev ix, const uint32_t *sel_pos, const uint32_t *sel_key, const float *sel_dist,
+                 uint32_t sel_stride, const uint32_t *sel_count, uint32_t k, uint32_t key_is_rank, uint64_t *out_ids,
+                 float *out_dist, uint32_t *out_count, const uint64_t *sel_ord, uint64_t *out_order, uint32_t nq) {
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const uint32_t n = min(sel_count[q], 64u * KPL);
+    const uint32_t *sp = sel_pos + (uint64_t)q * sel_stride, *sk = sel_key + (uint64_t)q * sel_stride;
+    const float *sd = sel_dist + (uint64_t)q * sel_stride;
+    uint64_t keys[KPL];
+#pragma unroll
+    for (int t = 0; t < KPL; ++t) {
+        const uint32_t i = t * 64 + lane;
+        keys[t] = ~0ull;
+        if (i < n) {
+            const uint32_t mid = key_is_rank ? 0u : (sk[i] & 0xFFFFu);
+            keys[t] = ((uint64_t)f32_key(sd[i]) << 30) | ((uint64_t)mid << 14) | i;
+        }
+    }
+    const uint32_t nout = min(n, k); // k <= 64: lane r keeps the r-th winner
+    uint64_t mine = ~0ull;
+    for (uint32_t r = 0; r < nout; ++r) {
+        uint64_t m = keys[0];
+#pragma unroll
+        for (int t = 1; t < KPL; ++t) m = keys[t] < m ? keys[t] : m;
+        uint64_t wm = m;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t other = (uint64_t)__shfl_xor((long long)wm, o, 64);
+            wm = other < wm ? other : wm;
+        }
+        if (lane == r) mine = wm;
+        if (m == wm) { // keys are distinct (the index is part of them): exactly one lane owns the minimum
+#pragma unroll
+            for (int t = 0; t < KPL; ++t) keys[t] = keys[t] == wm ? ~0ull : keys[t];
+        }
+    }
+    // all winners gathered at once: one chain of dependent loads for the wave, not one per round
+    for (uint32_t i = lane; i < k; i += 64) {
+        if (i < nout) {
+            const uint32_t j = (uint32_t)(mine & 0x3FFFu);
+            out_ids[(uint64_t)q * k + i] = ix.ids[sp[j]];
+            out_dist[(uint64_t)q * k + i] = sd[j];
+            if (out_order) out_order[(uint64_t)q * k + i] = sel_ord[(uint64_t)q * sel_stride + j];
+        } else {
+            out_ids[(uint64_t)q * k + i] = ~0ull;
+            out_dist[(uint64_t)q * k + i] = __builtin_inff();
+            if (out_order) out_order[(uint64_t)q * k + i] = ~0ull;
+        }
+    }
+    if (lane == 0 && out_count) out_count[q] = nout;
+}
+
 // Phase-1 selection listed in phase-1 order (stage output for parity tests): sorts the scan-order
 // selection by (key, scan order) and gathers pos/key/dist. One block per query.
 __global__ void __launch_bounds__(256)
