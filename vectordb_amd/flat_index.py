@@ -148,6 +148,61 @@ class FlatIndex:
         np.savez(path, dim=self.dim, metric=self.metric, code_kind=self.code_kind, threshold=np.float32(self.threshold),
                  **arrays)
 
+    _BIN_ARRAYS = (("centroids", np.float32), ("child_offsets", np.uint32), ("children", np.uint32), ("roots", np.uint32),
+                   ("vec_offsets", np.uint64), ("ids", np.uint64), ("vectors", np.float32))
+    _BIN_RABITQ = (("rabitq_rot_t", np.float32), ("rabitq_codes", np.uint32), ("rabitq_norm", np.float32),
+                   ("rabitq_ip_oo", np.float32))
+
+    def save_bin(self, path: str) -> None:
+        """The flat-index file the C++ host side reads (include/cuddle_index.hpp, FlatIndex::load):
+        "CUDDLEFI", u32 version 1, dim, metric, code_kind, n_nodes, n_roots, n_children, flags (bit 0
+        binary codes, bit 1 RaBitQ arrays), f32 threshold, 4 pad bytes, u64 n_vectors, then the arrays
+        in struct order, each padded to 8 bytes. Little-endian."""
+        x = self.normalised()
+        flags = (1 if x.codes is not None else 0) | (2 if x.rabitq_rot_t is not None else 0)
+        with open(path, "wb") as f:
+            f.write(b"CUDDLEFI")
+            f.write(np.array([1, x.dim, x.metric, x.code_kind, x.n_nodes, x.n_roots, x.children.shape[0], flags],
+                             dtype="<u4").tobytes())
+            f.write(np.array([x.threshold], dtype="<f4").tobytes() + b"\0" * 4)
+            f.write(np.array([x.n_vectors], dtype="<u8").tobytes())
+            todo = list(self._BIN_ARRAYS) + ([("codes", np.uint64)] if flags & 1 else []) + \
+                (list(self._BIN_RABITQ) if flags & 2 else [])
+            for name, dt in todo:
+                b = np.ascontiguousarray(getattr(x, name), dtype=np.dtype(dt).newbyteorder("<")).tobytes()
+                f.write(b + b"\0" * ((8 - len(b) % 8) % 8))
+
+    @staticmethod
+    def load_bin(path: str) -> "FlatIndex":
+        with open(path, "rb") as f:
+            buf = f.read()
+        assert buf[:8] == b"CUDDLEFI", "not a flat-index file"
+        h = np.frombuffer(buf, dtype="<u4", count=8, offset=8)
+        assert h[0] == 1, "unsupported flat-index version"
+        dim, metric, code_kind, n_nodes, n_roots, n_children, flags = (int(v) for v in h[1:])
+        thr = float(np.frombuffer(buf, dtype="<f4", count=1, offset=40)[0])
+        nvec = int(np.frombuffer(buf, dtype="<u8", count=1, offset=48)[0])
+        off = 56
+        counts = {"centroids": n_nodes * dim, "child_offsets": n_nodes + 1, "children": n_children, "roots": n_roots,
+                  "vec_offsets": n_nodes + 1, "ids": nvec, "vectors": nvec * dim, "codes": nvec * ((dim + 63) // 64),
+                  "rabitq_rot_t": dim * dim, "rabitq_codes": nvec * ((dim + 31) // 32), "rabitq_norm": nvec,
+                  "rabitq_ip_oo": nvec}
+        out = {}
+        todo = list(FlatIndex._BIN_ARRAYS) + ([("codes", np.uint64)] if flags & 1 else []) + \
+            (list(FlatIndex._BIN_RABITQ) if flags & 2 else [])
+        for name, dt in todo:
+            n = counts[name]
+            out[name] = np.frombuffer(buf, dtype=np.dtype(dt).newbyteorder("<"), count=n, offset=off).copy()
+            nbytes = n * np.dtype(dt).itemsize
+            off += nbytes + (8 - nbytes % 8) % 8
+        words, w32 = (dim + 63) // 64, (dim + 31) // 32
+        shaped = {"centroids": (-1, dim), "vectors": (-1, dim), "codes": (-1, words), "rabitq_rot_t": (dim, dim),
+                  "rabitq_codes": (-1, w32)}
+        for k2, shp in shaped.items():
+            if k2 in out:
+                out[k2] = out[k2].reshape(shp)
+        return FlatIndex(dim=dim, metric=metric, code_kind=code_kind, threshold=thr, **out).normalised()
+
     @staticmethod
     def load(path: str) -> "FlatIndex":
         z = np.load(path, allow_pickle=False)
