@@ -800,7 +800,9 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             uint32_t rg = 1;
             while (rg < 8 && (uint64_t)nq * v.dim * 4 / rg > (2u << 20) && gy >= 2 * rg) rg *= 2;
             const uint32_t rows_per = (gy + rg - 1) / rg, pgroups = 8 / rg;
-            if (cost1 < cost2)
+            static const char *force_nt = getenv("CUDDLE_GEMM_NT"); // tuning aid: 1 or 2 forces the column-tile width
+            const bool nt1 = force_nt ? force_nt[0] == '1' : cost1 < cost2;
+            if (nt1)
                 hipLaunchKernelGGL(route_gemm_kernel<1>, dim3(8 * rows_per * ((gx1 + pgroups - 1) / pgroups)), dim3(256),
                                    route_gemm_lds_bytes(1), s, pl.qcent, pl.qsq, g.table, g.sqn, nq, n, v.dim, v.metric, pl.fdist,
                                    pl.fstride, gx1, gy, rg);
