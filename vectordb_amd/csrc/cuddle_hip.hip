@@ -612,6 +612,10 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     // small per-query scans (few candidates): smaller blocks, more of them per CU, so that the
     // latency-bound prologue/selection phases of one query overlap the streaming of others
     pl.scan_threads = pl.cstride <= 16384 ? 256 : kScanThreads;
+    if (const char *e = getenv("CUDDLE_SCAN_THREADS")) {  // tuning aid; the kernels are bounded at 512 threads
+        const int t = atoi(e);
+        if (t >= 64 && t <= (int)kScanThreads && t % 64 == 0) pl.scan_threads = (uint32_t)t;
+    }
     if (v.code_kind == CUDDLE_CODE_BINARY) {
         const uint32_t esz = v.dim < 255 ? 1 : 2; // one byte per distance when dim < 255
         pl.dist_cap = std::min<uint32_t>(pl.cstride, kLdsDistCap * 2 / esz);
