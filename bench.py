@@ -336,6 +336,17 @@ def main():
                           "the code array is larger than the 256 MiB Infinity Cache; ") +
                          "achieved = algorithmic bytes per second, traffic = HBM bytes per launch from the PMC counters")
 
+    # routing filter: approximate (matrix-core) distances against the error bound its proof uses
+    route_filter = []
+    if world == 1:
+        q_host = queries[:256].cpu().numpy()
+        for level in range(dev_index.levels):
+            try:
+                ratio, err = dev_index.route_filter_error(q_host, probes, level)
+                route_filter.append({"level": level, "max_err_over_bound": ratio, "max_abs_err": err})
+            except _ffi.CuddleError:
+                pass  # narrow level (exact kernels only) or never a whole frontier
+
     cpu = None
     if not args.no_cpu_baseline and fi is not None:
         log("CPU baseline (oracle port, OpenMP)")
@@ -369,6 +380,7 @@ def main():
         "leaves_per_query": stats["leaves_searched"] / nq,
         "reranked_per_query": stats["vectors_reranked"] / nq,
         "route_fallbacks_per_batch": stats["route_fallbacks"],
+        "route_filter": route_filter,
         "max_candidates": stats["max_candidates"],
         "roofline": roofline,
         "cpu_baseline": cpu,

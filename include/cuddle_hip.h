@@ -208,6 +208,18 @@ cuddle_status cuddle_route_batch(cuddle_index *idx, const float *queries, uint32
                                  uint32_t dim, uint32_t probes_per_level, uint32_t flags,
                                  uint32_t *out_leaves, uint32_t leaf_stride,
                                  uint32_t *out_leaf_count);
+/* Diagnostic of the matrix-core routing filter (no counterpart in the reference, whose routing
+ * at hierarchical.rs:355-391 evaluates every distance exactly; here a level as wide as a whole
+ * frontier is first ranked by approximate distances, and the selection is accepted only where an
+ * error bound proves it equal to the exact one). For every (query, node of tree level `level`):
+ * err = |approximate distance - distance evaluated in f64|. *out_max_abs = the largest err,
+ * *out_max_ratio = the largest err / bound(query); the proof needs the ratio to stay below 1.
+ * CUDDLE_ERR_UNSUPPORTED when the level has no filter operands (fewer than 512 nodes) or can
+ * never be a whole frontier with this probes_per_level. */
+cuddle_status cuddle_route_filter_error(cuddle_index *idx, const float *queries,
+                                        uint32_t n_queries, uint32_t dim,
+                                        uint32_t probes_per_level, uint32_t level,
+                                        float *out_max_ratio, float *out_max_abs);
 /* collect_leaf_candidates (hierarchical.rs:618-641 / hierarchical_with_rabitq.rs:605-619)
  * for given leaf lists: per query the (position, code distance) pairs in scan order.
  * out_pos: [n_queries][cand_stride] leaf-contiguous positions (ids[pos] is the vector id);

@@ -72,12 +72,16 @@ def test_stage_outputs_match_oracle(gpu):
         assert np.array_equal(ids[i, :cnt[i]], t["ids"][:t["count"]])
 
 
-@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
-def test_mfma_routing_is_exact(gpu, metric):
-    """A level of > 512 nodes shared by all queries goes through the f32-MFMA contraction +
-    exact refinement; leaf lists must equal both the all-exact kernel's and the oracle's."""
+@pytest.mark.parametrize("metric,d,shift,scale", [("l2", 64, 0.0, 1.0), ("cosine", 64, 0.0, 1.0), ("dot", 64, 0.0, 1.0),
+                                                  ("l2", 37, 0.0, 1.0), ("cosine", 130, 0.0, 1.0), ("dot", 200, 0.0, 1.0),
+                                                  ("l2", 96, 50.0, 1.0), ("l2", 128, 0.0, 1000.0), ("cosine", 72, 3.0, 0.01)])
+def test_mfma_routing_is_exact(gpu, metric, d, shift, scale):
+    """A level of > 512 nodes shared by all queries goes through the matrix-core contraction (split
+    bf16 operands) + exact refinement; leaf lists must equal both the all-exact kernel's and the
+    oracle's, and the approximate distances must stay within the bound the proof of exactness uses
+    (also for data far from the origin and of large or small magnitude)."""
     orc = _oracle()
-    x = clustered(60000, 64, 300, 11, sigma=0.3)
+    x = ((clustered(60000, d, 300, 11, sigma=0.3) + np.float32(shift)) * np.float32(scale)).astype(np.float32)
     from vectordb_amd.builder import build_index
     fi = build_index(x, 100, 30, metric, 8, seed=3)
     widths = []
@@ -100,6 +104,8 @@ def test_mfma_routing_is_exact(gpu, metric):
         assert np.array_equal(lv_mfma[i, :lc_mfma[i]], t["leaves"]), i
     ids, dist, cnt, st = dev.search_batch(q, 10, probes, 5, want_stats=True)
     assert st["route_fallbacks"] <= q.shape[0] // 10, st
+    ratio, err = dev.route_filter_error(q, probes, 1)
+    assert 0.0 < ratio < 0.5, (ratio, err)
     _compare_full(fi, dev, q[:40], 10, probes, 5)
 
 

@@ -124,7 +124,8 @@ struct Plan {
     float *sel_dist = nullptr;
     // MFMA routing
     uint32_t kc_cap = 0;    // prefilter candidates per query (probes + margin)
-    float *qcent = nullptr, *qsq = nullptr, *rc_dist = nullptr, *rc_max = nullptr;
+    float *qsq = nullptr, *rc_dist = nullptr, *rc_max = nullptr;
+    uint16_t *qcent = nullptr; // centred queries as bf16 (hi, lo) pairs
     uint32_t *rc_pos = nullptr, *rflag = nullptr;
     uint32_t *order = nullptr; // queries by decreasing candidate count
     size_t bytes = 0;
@@ -134,7 +135,7 @@ struct Plan {
 struct LevelGemm {
     uint32_t n = 0;            // 0: contraction operands not built for this level
     uint32_t *nodes = nullptr; // [level width] node ids, breadth-first order (every level has it)
-    float *table = nullptr;    // [n][dim] centroid - mu
+    uint16_t *table = nullptr; // [n][split_kp(dim)] centroid - mu as bf16 (hi, lo) pairs, see level_table_kernel
     float *sqn = nullptr;      // [n]
     float *mu = nullptr;       // [dim]
     float max_sqn = 0.f;
@@ -436,7 +437,7 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
         ST_TRY(upload(ix, level_pos.data(), (size_t)n, &lp));
         v.level_pos = lp;
     }
-    if (D % 4 == 0) {
+    { // operands of the MFMA contraction for every level wide enough to use it
         for (uint32_t l = 0; l < n_levels; ++l) {
             const std::vector<uint32_t> &nodes = level_nodes[l];
             if (nodes.size() < kGemmMinWidth) continue;
@@ -453,10 +454,10 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
                 (void)hipDeviceSynchronize();
                 (void)hipFree(acc);
             }
-            ST_TRY(dev_alloc(ix, nodes.size() * (size_t)D, &g.table));
+            ST_TRY(dev_alloc(ix, nodes.size() * (size_t)split_kp(D) * 2, &g.table));
             ST_TRY(dev_alloc(ix, nodes.size(), &g.sqn));
             hipLaunchKernelGGL(level_table_kernel, dim3(((uint32_t)nodes.size() + 127) / 128), dim3(128), 0, 0, centroids,
-                               g.nodes, (uint32_t)nodes.size(), D, g.mu, g.table, g.sqn);
+                               g.nodes, (uint32_t)nodes.size(), D, split_kp(D), g.mu, g.table, g.sqn);
             std::vector<float> h(nodes.size());
             HIP_TRY(hipMemcpy(h.data(), g.sqn, nodes.size() * sizeof(float), hipMemcpyDeviceToHost));
             for (float x : h) g.max_sqn = std::max(g.max_sqn, x);
@@ -638,7 +639,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     size_t o_sp = carve(qc * pl.sstride * 4), o_sk = carve(qc * pl.sstride * 4), o_sd = carve(qc * pl.sstride * 4);
     size_t o_sc = carve(qc * 4), o_cc = carve(qc * 4);
     pl.kc_cap = (uint32_t)align_up((size_t)pl.probes + route_margin(pl.probes), 32);
-    size_t o_qcent = carve(qc * v.dim * 4), o_qsq = carve(qc * 4);
+    size_t o_qcent = carve(qc * split_kp(v.dim) * 4), o_qsq = carve(qc * 4);
     size_t o_rcp = carve(qc * pl.kc_cap * 4), o_rcd = carve(qc * pl.kc_cap * 4), o_rcm = carve(qc * 4), o_rfl = carve(qc * 4);
     size_t o_ord = carve(qc * 4);
     const size_t gw = (size_t)ix->max_parent_width + 1;
@@ -657,7 +658,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     pl.gdist = (uint16_t *)(b + o_gd);
     pl.sel_pos = (uint32_t *)(b + o_sp); pl.sel_key = (uint32_t *)(b + o_sk); pl.sel_dist = (float *)(b + o_sd);
     pl.sel_count = (uint32_t *)(b + o_sc); pl.cand_count = (uint32_t *)(b + o_cc);
-    pl.qcent = (float *)(b + o_qcent); pl.qsq = (float *)(b + o_qsq);
+    pl.qcent = (uint16_t *)(b + o_qcent); pl.qsq = (float *)(b + o_qsq);
     pl.rc_pos = (uint32_t *)(b + o_rcp); pl.rc_dist = (float *)(b + o_rcd); pl.rc_max = (float *)(b + o_rcm);
     pl.rflag = (uint32_t *)(b + o_rfl);
     pl.order = (uint32_t *)(b + o_ord);
@@ -723,6 +724,35 @@ static cuddle_status launch_quantize(cuddle_index *ix, const Plan &pl, const flo
 static void launch_query_norms(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, hipStream_t s) {
     if (ix->dev.metric != CUDDLE_METRIC_COSINE) return;
     hipLaunchKernelGGL(query_norm_kernel, dim3((nq * 4 + 255) / 256), dim3(256), 0, s, dq, nq, ix->dev.dim, pl.qnorm);
+}
+
+// Approximate distances of every query of the chunk to every node of a level that has contraction
+// operands: pl.fdist[q][0..g.n) and pl.qsq[q].
+static void launch_level_gemm(cuddle_index *ix, const Plan &pl, const LevelGemm &g, const float *dq, uint32_t nq, hipStream_t s) {
+    const IndexDev &v = ix->dev;
+    const uint32_t n = g.n;
+    const uint32_t kp = split_kp(v.dim);
+    hipLaunchKernelGGL(center_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, kp, pl.qcent, pl.qsq);
+    // column-tile width 128 or 64: whichever needs fewer rounds of blocks over the CUs (weighted by tile size)
+    const uint32_t gy = (nq + kGemmBM - 1) / kGemmBM, gx2 = (n + 127) / 128, gx1 = (n + 63) / 64;
+    const uint32_t cus = ix->n_cus;
+    const uint32_t cost2 = 2 * ((gx2 * gy + cus - 1) / cus), cost1 = (gx1 * gy + cus - 1) / cus;
+    // XCD row groups: as few as keep an XCD's share of A within half of its 4 MiB L2
+    uint32_t rg = 1;
+    while (rg < 8 && (uint64_t)nq * v.dim * 4 / rg > (2u << 20) && gy >= 2 * rg) rg *= 2;
+    const uint32_t rows_per = (gy + rg - 1) / rg, pgroups = 8 / rg;
+    static const char *force_nt = getenv("CUDDLE_GEMM_NT"); // tuning aid: 1 or 2 forces the column-tile width
+    const bool nt1 = force_nt ? force_nt[0] == '1' : cost1 < cost2;
+#define CUDDLE_ROUTE_GEMM(NT, BK, GX)                                                                                         \
+    hipLaunchKernelGGL((route_gemm_kernel<NT, BK>), dim3(8 * rows_per * (((GX) + pgroups - 1) / pgroups)), dim3(256),         \
+               (route_gemm_lds_bytes<NT, BK>()), s, (const u32x4 *)pl.qcent, pl.qsq, (const u32x4 *)g.table, g.sqn,   \
+               nq, n, kp, v.metric, pl.fdist, pl.fstride, (GX), gy, rg)
+    // K step: 64 halves the barriers of a long contraction; short ones are mostly epilogue and
+    // do better with the smaller LDS footprint (more blocks per CU) of 32
+    const bool k64 = kp >= 512;
+    if (nt1) { if (k64) CUDDLE_ROUTE_GEMM(1, 64, gx1); else CUDDLE_ROUTE_GEMM(1, 32, gx1); }
+    else     { if (k64) CUDDLE_ROUTE_GEMM(2, 64, gx2); else CUDDLE_ROUTE_GEMM(2, 32, gx2); }
+#undef CUDDLE_ROUTE_GEMM
 }
 
 // All tree levels (hierarchical.rs:349-423). Leaves end up in pl.leaves / pl.lcount.
@@ -795,25 +825,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound;
         if (use_gemm) {
             const uint32_t n = g.n, kc = std::min(n, pl.kc_cap);
-            hipLaunchKernelGGL(center_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, pl.qcent, pl.qsq);
-            // column-tile width 128 or 64: whichever needs fewer rounds of blocks over the CUs (weighted by tile size)
-            const uint32_t gy = (nq + kGemmBM - 1) / kGemmBM, gx2 = (n + 127) / 128, gx1 = (n + 63) / 64;
-            const uint32_t cus = ix->n_cus;
-            const uint32_t cost2 = 2 * ((gx2 * gy + cus - 1) / cus), cost1 = (gx1 * gy + cus - 1) / cus;
-            // XCD row groups: as few as keep an XCD's share of A within half of its 4 MiB L2
-            uint32_t rg = 1;
-            while (rg < 8 && (uint64_t)nq * v.dim * 4 / rg > (2u << 20) && gy >= 2 * rg) rg *= 2;
-            const uint32_t rows_per = (gy + rg - 1) / rg, pgroups = 8 / rg;
-            static const char *force_nt = getenv("CUDDLE_GEMM_NT"); // tuning aid: 1 or 2 forces the column-tile width
-            const bool nt1 = force_nt ? force_nt[0] == '1' : cost1 < cost2;
-            if (nt1)
-                hipLaunchKernelGGL(route_gemm_kernel<1>, dim3(8 * rows_per * ((gx1 + pgroups - 1) / pgroups)), dim3(256),
-                                   route_gemm_lds_bytes(1), s, pl.qcent, pl.qsq, g.table, g.sqn, nq, n, v.dim, v.metric, pl.fdist,
-                                   pl.fstride, gx1, gy, rg);
-            else
-                hipLaunchKernelGGL(route_gemm_kernel<2>, dim3(8 * rows_per * ((gx2 + pgroups - 1) / pgroups)), dim3(256),
-                                   route_gemm_lds_bytes(2), s, pl.qcent, pl.qsq, g.table, g.sqn, nq, n, v.dim, v.metric, pl.fdist,
-                                   pl.fstride, gx2, gy, rg);
+            launch_level_gemm(ix, pl, g, dq, nq, s);
             if (n <= (uint32_t)kPrefKpt * 128)
                 hipLaunchKernelGGL(route_prefilter_reg_kernel<128>, dim3(nq), dim3(128), 0, s, pl.fdist, pl.fstride, n, kc,
                                    pl.rc_pos, pl.kc_cap, pl.rc_max);
@@ -1191,6 +1203,50 @@ extern "C" cuddle_status cuddle_route_batch(cuddle_index *idx, const float *quer
                             qc, hipMemcpyDeviceToHost));
     }
     return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_route_filter_error(cuddle_index *idx, const float *queries, uint32_t n_queries, uint32_t dim,
+                                                   uint32_t probes_per_level, uint32_t level, float *out_max_ratio,
+                                                   float *out_max_abs) {
+    if (!idx) return fail(CUDDLE_ERR_BAD_ARG, "index is null");
+    if (!queries || !out_max_ratio || !out_max_abs) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    if (dim != idx->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, idx->dev.dim);
+    if (probes_per_level == 0) return fail(CUDDLE_ERR_BAD_ARG, "probes_per_level must be >= 1");
+    if (level >= idx->n_levels || idx->lvl[level].n == 0)
+        return fail(CUDDLE_ERR_UNSUPPORTED, "level %u has no contraction operands (narrower than %u nodes)", level, kGemmMinWidth);
+    *out_max_ratio = *out_max_abs = 0.f;
+    if (n_queries == 0) return CUDDLE_OK;
+    Plan pl;
+    ST_TRY(make_plan(idx, n_queries, 1, probes_per_level, 1, 0, pl));
+    const LevelGemm &g = idx->lvl[level];
+    if (g.n > pl.fstride) return fail(CUDDLE_ERR_UNSUPPORTED, "level %u is never a whole frontier with probes_per_level %u", level, probes_per_level);
+    HostIO io;
+    ST_TRY(carve_io(idx, pl.qc, dim, 1, 0, io, nullptr));
+    uint32_t *d_max = nullptr; // [0] = max ratio, [1] = max absolute error, as the bits of non-negative floats
+    HIP_TRY(hipMalloc((void **)&d_max, 8));
+    cuddle_status st = CUDDLE_OK;
+    auto body = [&]() -> cuddle_status {
+        HIP_TRY(hipMemset(d_max, 0, 8));
+        for (uint32_t q0 = 0; q0 < n_queries; q0 += pl.qc) {
+            const uint32_t qc = std::min(pl.qc, n_queries - q0);
+            HIP_TRY(hipMemcpy(io.q, queries + (uint64_t)q0 * dim, (size_t)qc * dim * 4, hipMemcpyHostToDevice));
+            launch_level_gemm(idx, pl, g, io.q, qc, nullptr);
+            hipLaunchKernelGGL(route_filter_error_kernel, dim3((g.n + 255) / 256, qc), dim3(256), 0, nullptr, idx->dev, io.q, g.nodes, g.n,
+                               pl.fdist, pl.fstride, pl.qsq, g.max_sqn, d_max);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(nullptr));
+        }
+        uint32_t h[2];
+        HIP_TRY(hipMemcpy(h, d_max, 8, hipMemcpyDeviceToHost));
+        memcpy(out_max_ratio, &h[0], 4);
+        memcpy(out_max_abs, &h[1], 4);
+        return CUDDLE_OK;
+    };
+    st = body();
+    (void)hipFree(d_max);
+    return st;
 }
 
 // Uploads caller-given leaf lists of one chunk into the plan's leaf buffers.

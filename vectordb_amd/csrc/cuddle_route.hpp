@@ -685,35 +685,65 @@ route_dist_grouped_kernel(IndexDev ix, const float *queries, const uint32_t *lev
 // MFMA path
 // ---------------------------------------------------------------------------------------------
 
-// Per-level table for the contraction (built once per index): row j = centroid of the j-th node
-// of the level (breadth-first order = the frontier order every query sees when all earlier
-// levels keep all their nodes) minus mu (L2: the level's mean centroid, which keeps the norms and
-// so the rounding error of the norm expansion small; other metrics: mu = 0), plus its squared
-// norm as a fused-multiply-add chain.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kGemmBM = 128;
+
+// The contraction runs on the bf16 matrix cores (16 times the rate of the f32 ones) at close to f32
+// accuracy: an f32 value x is carried as two bf16 numbers, hi = bf16(x) and lo = bf16(x - hi), both
+// rounded to nearest even, so |x - hi - lo| <= 2^-16 |x|. Of the four partial products of x y the
+// kernel sums hi*hi on one accumulator and hi*lo + lo*hi on a second one (bf16 products are exact in
+// f32); what it drops (lo*lo and the two residuals) is at most 3.0001 * 2^-16 |x y| per product.
+// Split operand layout, per row: K' = K rounded up to 64 values, stored as K'/8 groups of 32 bytes
+// = the 8 hi halves followed by the 8 lo halves of the same 8 values; zeros beyond K.
+
+inline uint32_t split_kp(uint32_t dim) { return (dim + 63) / 64 * 64; } // K' of a split row
+
+__device__ __forceinline__ uint32_t bf16_round(float x) {
+    const uint32_t b = __float_as_uint(x);
+    return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
+}
+
+__device__ __forceinline__ void bf16_split_store(uint16_t *row, uint32_t i, float v) {
+    const uint32_t hi = bf16_round(v);
+    const uint32_t lo = bf16_round(v - __uint_as_float(hi << 16));
+    uint16_t *g = row + (i >> 3) * 16 + (i & 7);
+    g[0] = (uint16_t)hi;
+    g[8] = (uint16_t)lo;
+}
+
+// Per-level table for the contraction (built once per index), in split form: row j = centroid of
+// the j-th node of the level (breadth-first order = the frontier order every query sees when all
+// earlier levels keep all their nodes) minus mu (L2: the level's mean centroid, which keeps the norms
+// and so the rounding error of the norm expansion small; other metrics: mu = 0), plus the squared
+// norm of the f32 row as a fused-multiply-add chain. One thread per row.
 __global__ void level_table_kernel(const float *centroids, const uint32_t *level_nodes, uint32_t n, uint32_t dim,
-                                   const float *mu, float *table, float *sqn) {
+                                         uint32_t kp, const float *mu, uint16_t *table, float *sqn) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const float *c = centroids + (uint64_t)level_nodes[j] * dim;
-    float *t = table + (uint64_t)j * dim;
+    uint16_t *t = table + (uint64_t)j * kp * 2;
     float s = 0.f;
     for (uint32_t i = 0; i < dim; ++i) {
         float v = c[i] - mu[i];
-        t[i] = v;
+        bf16_split_store(t, i, v);
         s = __builtin_fmaf(v, v, s);
     }
+    for (uint32_t i = dim; i < kp; ++i) bf16_split_store(t, i, 0.f);
     sqn[j] = s;
 }
 
-// q' = q - mu and |q'|^2 for every query of the batch (one wave per query).
+// q' = q - mu in split form and |q'|^2 for every query of the batch (one wave per query).
 __global__ void __launch_bounds__(256)
-center_queries_kernel(const float *queries, const float *mu, uint32_t nq, uint32_t dim, float *out, float *sqn) {
+center_queries_kernel(const float *queries, const float *mu, uint32_t nq, uint32_t dim, uint32_t kp, uint16_t *out,
+                            float *sqn) {
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq) return;
+    uint16_t *row = out + (uint64_t)q * kp * 2;
     float s = 0.f;
-    for (uint32_t i = lane; i < dim; i += 64) {
-        float v = queries[(uint64_t)q * dim + i] - mu[i];
-        out[(uint64_t)q * dim + i] = v;
+    for (uint32_t i = lane; i < kp; i += 64) {
+        float v = i < dim ? queries[(uint64_t)q * dim + i] - mu[i] : 0.f;
+        bf16_split_store(row, i, v);
         s = __builtin_fmaf(v, v, s);
     }
 #pragma unroll
@@ -721,112 +751,107 @@ center_queries_kernel(const float *queries, const float *mu, uint32_t nq, uint32
     if (lane == 0) sqn[q] = s;
 }
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kGemmBM = 128, kGemmBK = 32;
-constexpr int kGemmLdsRow = 20; // 16 floats of one (row, k-parity) + 4 pad: conflict-free ds_read_b128
-inline size_t route_gemm_lds_bytes(int nt) { return (size_t)2 /*parity*/ * (kGemmBM + 64 * nt) * kGemmLdsRow * sizeof(float); }
+template <int NT, int BK>
+constexpr size_t route_gemm_lds_bytes() { return (size_t)(kGemmBM + 64 * NT) * (BK / 4 + 1) * 16; }
 
 // Approximate distances of every query to every node of one level:
-//   S = A * B^T on the f32 matrix cores (A = centred queries [M][K], B = level table [N][K]),
+//   S = A * B^T from the split operands (A = centred queries [M][K'], B = level table [N][K']):
+//       S = sum_k (ah bh) + sum_k (ah bl + al bh)   (v_mfma_f32_32x32x16_bf16, two accumulators per tile)
 //   L2:     d~ = (|a|^2 + |b|^2) - 2 S
 //   DOT:    d~ = -S
 //   COSINE: d~ = 1 - S / (|a| |b|)
-// Block tile 128 x (64 NT), K step 32, 4 waves as 2 x 2, each wave 64 x (32 NT) = 2 x NT MFMA tiles
-// of 32 x 32 (v_mfma_f32_32x32x2_f32: lane l supplies A[row l&31][k = l>>5] and B[k = l>>5][col l&31]).
-// NT = 2 has the higher arithmetic intensity, NT = 1 twice the blocks: the host picks whichever
-// leaves fewer idle CUs in the last round of blocks.
-// LDS image per operand: [k parity h][row][s] with k = 2s + h, so a lane reads its 16 k-values of
-// a K step with four ds_read_b128. Global tiles are prefetched into registers one K step ahead.
+// Block tile 128 x (64 NT), K step BK (32 or 64), 4 waves as 2 x 2, each wave 64 x (32 NT) = 2 x NT
+// MFMA tiles of 32 x 32. NT = 2 has the higher arithmetic intensity, NT = 1 twice the blocks: the host
+// picks whichever leaves fewer idle CUs in the last round of blocks.
+// LDS image per operand: [row][BK/8 groups of (8 hi, 8 lo)] in 16-byte units with one unit of padding
+// per row, so that the 32 rows a half-wave reads with ds_read_b128 fall into distinct bank groups. Which
+// 8 values of a 16-value step go to which half-wave is the same for A and B, which is all a dot
+// product needs. Global tiles are prefetched into registers one K step ahead.
 // Blocks are numbered for the XCDs' private L2s (block id % 8 = XCD): the 8 XCDs form rg row
 // groups x (8 / rg) panel groups; an XCD works on its row group's tiles of A (kept in its L2: the
 // host picks rg so that they take at most half of it) against its panel group's column panels of
 // B, the row tiles of one panel running together so that the panel is fetched once.
-// K must be a multiple of 4. out: [M][ostride]. grid = 8 * ceil(gy / rg) * ceil(gx / (8 / rg)).
-template <int NT>
-__global__ void __launch_bounds__(256, NT == 1 ? 5 : 3) // blocks of 4 waves per CU the register allocation must allow
-route_gemm_kernel(const float *A, const float *Asq, const float *B, const float *Bsq, uint32_t M, uint32_t N,
-                  uint32_t K, uint32_t metric, float *out, uint32_t ostride, uint32_t gx, uint32_t gy, uint32_t rg) {
-    constexpr int BN = 64 * NT;
+// out: [M][ostride]. grid = 8 * ceil(gy / rg) * ceil(gx / (8 / rg)).
+template <int NT, int BK>
+__global__ void __launch_bounds__(256, NT == 1 ? 3 : 2)
+route_gemm_kernel(const u32x4 *A, const float *Asq, const u32x4 *B, const float *Bsq, uint32_t M, uint32_t N,
+                        uint32_t kp, uint32_t metric, float *out, uint32_t ostride, uint32_t gx, uint32_t gy, uint32_t rg) {
+    constexpr int BN = 64 * NT, CH = BK / 4, RS = CH + 1, RPP = 256 / CH, PA = kGemmBM / RPP, PB = BN / RPP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *As = reinterpret_cast<float *>(smem);            // [2][128][20]
-    float *Bs = As + 2 * kGemmBM * kGemmLdsRow;             // [2][BN][20]
+    u32x4 *As = reinterpret_cast<u32x4 *>(smem); // [128][RS]
+    u32x4 *Bs = As + kGemmBM * RS;               // [BN][RS]
     const uint32_t id = blockIdx.x;
     const uint32_t xcd = id & 7, local = id >> 3, pgroups = 8 / rg, rows_per = (gy + rg - 1) / rg;
     const uint32_t by = (xcd % rg) * rows_per + local % rows_per, bx = (local / rows_per) * pgroups + xcd / rg;
     if (bx >= gx || by >= gy) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t wr = w >> 1, wc = w & 1, r = lane & 31, h = lane >> 5;
-    // global -> register staging: thread covers rows (tid>>3) + 32 i, floats 4 (tid&7) .. +3
-    const uint32_t lr = tid >> 3, lc4 = tid & 7;
-    const float *ga[4], *gb[2 * NT];
+    const uint32_t lr = tid / CH, c = tid % CH, rowu = kp / 4; // 16-byte units per split row
+    const u32x4 *ga[PA], *gb[PB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ga[i] = A + (uint64_t)min(by * kGemmBM + lr + 32 * i, M - 1) * K + 4 * lc4;
+    for (int i = 0; i < PA; ++i) ga[i] = A + (uint64_t)min(by * kGemmBM + lr + RPP * i, M - 1) * rowu + c;
 #pragma unroll
-    for (int i = 0; i < 2 * NT; ++i) gb[i] = B + (uint64_t)min(bx * BN + lr + 32 * i, N - 1) * K + 4 * lc4;
-    float4 pa[4], pb[2 * NT];
-    auto load_tile = [&](uint32_t k0) {
-        const bool in = k0 + 4 * lc4 < K;
+    for (int i = 0; i < PB; ++i) gb[i] = B + (uint64_t)min(bx * BN + lr + RPP * i, N - 1) * rowu + c;
+    u32x4 pa[PA], pb[PB];
+    auto load_tile = [&](uint32_t u0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pa[i] = in ? *reinterpret_cast<const float4 *>(ga[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < PA; ++i) pa[i] = ga[i][u0];
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) pb[i] = in ? *reinterpret_cast<const float4 *>(gb[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < PB; ++i) pb[i] = gb[i][u0];
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t row = lr + 32 * i;
-            *reinterpret_cast<float2 *>(As + (0 * kGemmBM + row) * kGemmLdsRow + 2 * lc4) = make_float2(pa[i].x, pa[i].z);
-            *reinterpret_cast<float2 *>(As + (1 * kGemmBM + row) * kGemmLdsRow + 2 * lc4) = make_float2(pa[i].y, pa[i].w);
-        }
+        for (int i = 0; i < PA; ++i) As[(lr + RPP * i) * RS + c] = pa[i];
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) {
-            const uint32_t row = lr + 32 * i;
-            *reinterpret_cast<float2 *>(Bs + (0 * BN + row) * kGemmLdsRow + 2 * lc4) = make_float2(pb[i].x, pb[i].z);
-            *reinterpret_cast<float2 *>(Bs + (1 * BN + row) * kGemmLdsRow + 2 * lc4) = make_float2(pb[i].y, pb[i].w);
-        }
+        for (int i = 0; i < PB; ++i) Bs[(lr + RPP * i) * RS + c] = pb[i];
     };
-    f32x16 acc[2][NT];
+    f32x16 acc[2][NT], cor[2][NT];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = cor[mt][nt][e] = 0.f;
     load_tile(0);
-    for (uint32_t k0 = 0; k0 < K; k0 += kGemmBK) {
+    for (uint32_t u0 = 0; u0 < rowu; u0 += CH) {
         __syncthreads(); // previous step's LDS reads are done
         store_tile();
         __syncthreads();
-        if (k0 + kGemmBK < K) load_tile(k0 + kGemmBK);
-        float4 fa[2][4], fb[NT][4];
+        if (u0 + CH < rowu) load_tile(u0 + CH);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float4 *p4 = reinterpret_cast<const float4 *>(As + (h * kGemmBM + wr * 64 + t * 32 + r) * kGemmLdsRow);
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const uint32_t g = 2 * (2 * ks + h); // this half-wave's group of 8 values: hi unit, then lo unit
+            bf16x8 ah[2], al[2], bh[NT], bl[NT];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) fa[t][s4] = p4[s4];
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float4 *p4 = reinterpret_cast<const float4 *>(Bs + (h * BN + wc * 32 * NT + t * 32 + r) * kGemmLdsRow);
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) fb[t][s4] = p4[s4];
-        }
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float av[2], bv[NT];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) av[t] = e == 0 ? fa[t][s4].x : e == 1 ? fa[t][s4].y : e == 2 ? fa[t][s4].z : fa[t][s4].w;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bv[t] = e == 0 ? fb[t][s4].x : e == 1 ? fb[t][s4].y : e == 2 ? fb[t][s4].z : fb[t][s4].w;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+            for (int t = 0; t < 2; ++t) {
+                const u32x4 *p = As + (wr * 64 + t * 32 + r) * RS + g;
+                ah[t] = __builtin_bit_cast(bf16x8, p[0]);
+                al[t] = __builtin_bit_cast(bf16x8, p[1]);
             }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const u32x4 *p = Bs + (wc * 32 * NT + t * 32 + r) * RS + g;
+                bh[t] = __builtin_bit_cast(bf16x8, p[0]);
+                bl[t] = __builtin_bit_cast(bf16x8, p[1]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    cor[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], cor[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    cor[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], cor[mt][nt], 0, 0, 0);
         }
     }
     // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
@@ -841,7 +866,7 @@ route_gemm_kernel(const float *A, const float *Asq, const float *B, const float 
             for (int e = 0; e < 16; ++e) {
                 const uint32_t gm = by * kGemmBM + wr * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (gm >= M) continue;
-                const float s = acc[mt][nt][e], as = Asq[gm];
+                const float s = acc[mt][nt][e] + cor[mt][nt][e], as = Asq[gm];
                 float d;
                 if (metric == kMetricL2) d = __builtin_fmaf(-2.0f, s, as + bs);
                 else if (metric == kMetricDot) d = -s;
@@ -854,13 +879,43 @@ route_gemm_kernel(const float *A, const float *Asq, const float *B, const float 
 // Bound on |d~ - d| (d = the exact-order f32 distance) for one query against any node of the
 // level: any-order f32 dot products of length D are within gamma_D * sum|x_i y_i| of the true
 // value, the exact-order L2 within gamma_(D/16+8) of it, centring adds u-relative component
-// errors; collected conservatively as (2.5 D + 64) * 2^-24 times
+// errors, and the split operands drop at most 3.0001 * 2^-16 sum|x_i y_i|; collected conservatively
+// as ((2.5 D + 64) * 2^-24 + 3.25 * 2^-16) times
 //   L2: |q'|^2 + max|c'|^2      DOT: |q| max|c|      COSINE: 1.
+// (L2: the error of S enters d~ twice, and 2 sum|x_i y_i| <= |q'|^2 + |c'|^2.)
 __device__ __forceinline__ float route_error_bound(uint32_t metric, uint32_t dim, float qsq, float max_csq) {
-    const float cu = (2.5f * (float)dim + 64.0f) * 5.9604645e-8f;
+    const float cu = (2.5f * (float)dim + 64.0f) * 5.9604645e-8f + 3.25f * 1.52587890625e-5f;
     if (metric == kMetricL2) return cu * (qsq + max_csq);
     if (metric == kMetricDot) return cu * sqrtf(qsq) * sqrtf(max_csq);
     return cu;
+}
+
+// Diagnostic: how close the approximate distances come to the bound the exactness proof relies on.
+// For every (query, node of the level): err = |d~ - d| with d evaluated in f64 from the original
+// vectors; dmax[0] = max err / route_error_bound(query), dmax[1] = max err (bits of non-negative
+// floats, so the unsigned maximum orders them). grid = (ceil(n/256), nq), block 256.
+__global__ void __launch_bounds__(256)
+route_filter_error_kernel(IndexDev ix, const float *queries, const uint32_t *level_nodes, uint32_t n, const float *fdist,
+                          uint32_t fstride, const float *qsq, float max_csq, uint32_t *dmax) {
+    const uint32_t q = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x, D = ix.dim;
+    if (j >= n) return;
+    const float *a = queries + (uint64_t)q * D, *b = ix.centroids + (uint64_t)level_nodes[j] * D;
+    double dot = 0.0, aa = 0.0, bb = 0.0, l2 = 0.0;
+    for (uint32_t i = 0; i < D; ++i) {
+        const double x = a[i], y = b[i];
+        dot += x * y;
+        aa += x * x;
+        bb += y * y;
+        l2 += (x - y) * (x - y);
+    }
+    double d;
+    if (ix.metric == kMetricL2) d = l2;
+    else if (ix.metric == kMetricDot) d = -dot;
+    else d = (aa == 0.0 || bb == 0.0) ? 1.0 : 1.0 - dot / (sqrt(aa) * sqrt(bb));
+    const float err = (float)fabs((double)fdist[(uint64_t)q * fstride + j] - d);
+    const float bound = route_error_bound(ix.metric, D, qsq[q], max_csq);
+    atomicMax(&dmax[0], __float_as_uint(bound > 0.f ? err / bound : (err > 0.f ? 3.4e38f : 0.f)));
+    atomicMax(&dmax[1], __float_as_uint(err));
 }
 
 // Per query: the kc smallest approximate distances of the level (positions in level order) and

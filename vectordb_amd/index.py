@@ -192,6 +192,16 @@ class DeviceIndex:
                                                 _ffi.ptr(leaves), stride, _ffi.ptr(count)))
         return leaves, count
 
+    def route_filter_error(self, queries: np.ndarray, probes_per_level: int, level: int):
+        """(max err / bound, max err) of the routing filter's approximate distances on one tree level."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        nq, dim = q.shape
+        ratio = np.zeros(1, dtype=np.float32)
+        err = np.zeros(1, dtype=np.float32)
+        _ffi.check(self._lib.cuddle_route_filter_error(self._handle, _ffi.ptr(q), nq, dim, probes_per_level, level,
+                                                       _ffi.ptr(ratio), _ffi.ptr(err)))
+        return float(ratio[0]), float(err[0])
+
     def scan_batch(self, queries: np.ndarray, leaves: np.ndarray, leaf_count: np.ndarray):
         q = np.ascontiguousarray(queries, dtype=np.float32)
         nq, dim = q.shape
