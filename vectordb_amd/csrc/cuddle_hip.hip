@@ -275,8 +275,7 @@ __global__ void stats_accum_kernel(const uint32_t *lcount, const uint32_t *cand_
         atomicMax(&st->max_leaves, ml);
     }
 }
-// Sum of squares of each centroid as a k-ordered fused-multiply-add chain (the form the f32 MFMA
-// contraction produces), used by the MFMA routing filter.
+// Sum of squares of each centroid as a k-ordered fused-multiply-add chain, used by the MFMA routing filter.
 __global__ void centroid_sqnorm_kernel(const float *c, uint32_t n, uint32_t dim, float *out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -733,25 +732,19 @@ static void launch_level_gemm(cuddle_index *ix, const Plan &pl, const LevelGemm 
     const uint32_t n = g.n;
     const uint32_t kp = split_kp(v.dim);
     hipLaunchKernelGGL(center_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, kp, pl.qcent, pl.qsq);
-    // column-tile width 128 or 64: whichever needs fewer rounds of blocks over the CUs (weighted by tile size)
-    const uint32_t gy = (nq + kGemmBM - 1) / kGemmBM, gx2 = (n + 127) / 128, gx1 = (n + 63) / 64;
-    const uint32_t cus = ix->n_cus;
-    const uint32_t cost2 = 2 * ((gx2 * gy + cus - 1) / cus), cost1 = (gx1 * gy + cus - 1) / cus;
+    const uint32_t gy = (nq + kGemmBM - 1) / kGemmBM, gx = (n + 63) / 64;
     // XCD row groups: as few as keep an XCD's share of A within half of its 4 MiB L2
     uint32_t rg = 1;
-    while (rg < 8 && (uint64_t)nq * v.dim * 4 / rg > (2u << 20) && gy >= 2 * rg) rg *= 2;
+    while (rg < 8 && (uint64_t)nq * kp * 4 / rg > (2u << 20) && gy >= 2 * rg) rg *= 2;
     const uint32_t rows_per = (gy + rg - 1) / rg, pgroups = 8 / rg;
-    static const char *force_nt = getenv("CUDDLE_GEMM_NT"); // tuning aid: 1 or 2 forces the column-tile width
-    const bool nt1 = force_nt ? force_nt[0] == '1' : cost1 < cost2;
-#define CUDDLE_ROUTE_GEMM(NT, BK, GX)                                                                                         \
-    hipLaunchKernelGGL((route_gemm_kernel<NT, BK>), dim3(8 * rows_per * (((GX) + pgroups - 1) / pgroups)), dim3(256),         \
-               (route_gemm_lds_bytes<NT, BK>()), s, (const u32x4 *)pl.qcent, pl.qsq, (const u32x4 *)g.table, g.sqn,   \
-               nq, n, kp, v.metric, pl.fdist, pl.fstride, (GX), gy, rg)
-    // K step: 64 halves the barriers of a long contraction; short ones are mostly epilogue and
-    // do better with the smaller LDS footprint (more blocks per CU) of 32
-    const bool k64 = kp >= 512;
-    if (nt1) { if (k64) CUDDLE_ROUTE_GEMM(1, 64, gx1); else CUDDLE_ROUTE_GEMM(1, 32, gx1); }
-    else     { if (k64) CUDDLE_ROUTE_GEMM(2, 64, gx2); else CUDDLE_ROUTE_GEMM(2, 32, gx2); }
+#define CUDDLE_ROUTE_GEMM(NT, BK)                                                                                            \
+    hipLaunchKernelGGL((route_gemm_kernel<NT, BK>), dim3(8 * rows_per * ((gx + pgroups - 1) / pgroups)), dim3(256),          \
+                       (route_gemm_lds_bytes<NT, BK>()), s, (const u32x4 *)pl.qcent, pl.qsq, (const u32x4 *)g.table, g.sqn,  \
+                       nq, n, kp, v.metric, pl.fdist, pl.fstride, gx, gy, rg)
+    // Column tiles of 64 (NT = 1): the wider tile's better reuse never made up for its fewer, longer
+    // blocks on the measured shapes. K step: 64 halves the barriers of a long contraction; short ones
+    // are mostly epilogue and do better with the smaller LDS footprint (more blocks per CU) of 32.
+    if (kp >= 512) CUDDLE_ROUTE_GEMM(1, 64); else CUDDLE_ROUTE_GEMM(1, 32);
 #undef CUDDLE_ROUTE_GEMM
 }
 
@@ -826,18 +819,23 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         if (use_gemm) {
             const uint32_t n = g.n, kc = std::min(n, pl.kc_cap);
             launch_level_gemm(ix, pl, g, dq, nq, s);
-            if (n <= (uint32_t)kPrefKpt * 128)
-                hipLaunchKernelGGL(route_prefilter_reg_kernel<128>, dim3(nq), dim3(128), 0, s, pl.fdist, pl.fstride, n, kc,
-                                   pl.rc_pos, pl.kc_cap, pl.rc_max);
-            else if (n <= (uint32_t)kPrefKpt * 256)
-                hipLaunchKernelGGL(route_prefilter_reg_kernel<256>, dim3(nq), dim3(256), 0, s, pl.fdist, pl.fstride, n, kc,
-                                   pl.rc_pos, pl.kc_cap, pl.rc_max);
-            else if (n <= (uint32_t)kPrefKpt * 512)
-                hipLaunchKernelGGL(route_prefilter_reg_kernel<512>, dim3(nq), dim3(512), 0, s, pl.fdist, pl.fstride, n, kc,
-                                   pl.rc_pos, pl.kc_cap, pl.rc_max);
+#define CUDDLE_PREFILTER(T, K)                                                                                                \
+    hipLaunchKernelGGL((route_prefilter_reg_kernel<T, K>), dim3(nq), dim3(T), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,    \
+                       pl.kc_cap, pl.rc_max)
+            // keys in registers, as few per thread as the level's width allows (unused key slots still cost
+            // their predicated instructions in every pass)
+            if (n <= 128 * 8) CUDDLE_PREFILTER(128, 8);
+            else if (n <= 256 * 8) CUDDLE_PREFILTER(256, 8);
+            else if (n <= 256 * 16) CUDDLE_PREFILTER(256, 16);
+            else if (n <= 256 * 24) CUDDLE_PREFILTER(256, 24);
+            else if (n <= 512 * 16) CUDDLE_PREFILTER(512, 16);
+            else if (n <= 512 * 20) CUDDLE_PREFILTER(512, 20);
+            else if (n <= 512 * 24) CUDDLE_PREFILTER(512, 24);
+            else if (n <= 512 * 32) CUDDLE_PREFILTER(512, 32);
             else
                 hipLaunchKernelGGL(route_prefilter_kernel, dim3(nq), dim3(256), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,
                                    pl.kc_cap, pl.rc_max);
+#undef CUDDLE_PREFILTER
             hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                g.nodes, pl.rc_pos, pl.kc_cap, kc, pl.rc_dist, pl.qnorm);
             hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(kc), pl.probes), s,
@@ -865,6 +863,10 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             CUDDLE_SELECT_REG(256, 24);
         else if (!keep_all && bound <= 256 * 32)
             CUDDLE_SELECT_REG(256, 32);
+        else if (!keep_all && bound <= 512 * 20)
+            CUDDLE_SELECT_REG(512, 20);
+        else if (!keep_all && bound <= 512 * 24)
+            CUDDLE_SELECT_REG(512, 24);
         else if (!keep_all && bound <= 512 * 32)
             CUDDLE_SELECT_REG(512, 32);
         else

@@ -6,9 +6,9 @@
 //    arithmetic the reference uses for that frontier size, route_select_kernel picks the nodes.
 //
 //  * MFMA path (a level whose frontier is the same node list for every query and wider than
-//    probes_per_level): the query x centroid contraction runs on the f32 matrix cores
-//    (v_mfma_f32_32x32x2_f32) with precomputed squared norms and gives an *approximate* distance
-//    d~ for every (query, node); the probes + margin smallest d~ per query are then re-evaluated
+//    probes_per_level): the query x centroid contraction runs on the bf16 matrix cores
+//    (v_mfma_f32_32x32x16_bf16 over operands split into bf16 hi and lo parts, f32 accumulation)
+//    with precomputed squared norms and gives an *approximate* distance d~ for every (query, node); the probes + margin smallest d~ per query are then re-evaluated
 //    exactly, sorted, and accepted only if the error bound proves that no unselected node can
 //    belong to the exact top `probes`. Queries that fail the proof are re-routed by the exact path.
 #pragma once
@@ -764,8 +764,7 @@ constexpr size_t route_gemm_lds_bytes() { return (size_t)(kGemmBM + 64 * NT) * (
 //   DOT:    d~ = -S
 //   COSINE: d~ = 1 - S / (|a| |b|)
 // Block tile 128 x (64 NT), K step BK (32 or 64), 4 waves as 2 x 2, each wave 64 x (32 NT) = 2 x NT
-// MFMA tiles of 32 x 32. NT = 2 has the higher arithmetic intensity, NT = 1 twice the blocks: the host
-// picks whichever leaves fewer idle CUs in the last round of blocks.
+// MFMA tiles of 32 x 32 (NT = 2 has the higher arithmetic intensity, NT = 1 twice the blocks).
 // LDS image per operand: [row][BK/8 groups of (8 hi, 8 lo)] in 16-byte units with one unit of padding
 // per row, so that the 32 rows a half-wave reads with ds_read_b128 fall into distinct bank groups. Which
 // 8 values of a 16-value step go to which half-wave is the same for A and B, which is all a dot
@@ -937,14 +936,12 @@ route_prefilter_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_
     if (threadIdx.x == 0) cand_max[q] = f32_from_key(T);
 }
 
-constexpr int kPrefKpt = 32; // register-resident prefilter: n <= 32 * THREADS
-
-// Same result as route_prefilter_kernel for levels of at most kPrefKpt * THREADS nodes, with
+// Same result as route_prefilter_kernel for levels of at most KPT * THREADS nodes, with
 // the keys read once and kept in registers: block min/max first (radix passes whose digit is the
 // same for every key are skipped: no counting, no same-address atomics), then the remaining
 // passes from registers; the winners are written in any order (which ties at the threshold are
 // kept is free: every unselected node still has d~ >= cand_max, which is all the proof needs).
-template <int THREADS>
+template <int THREADS, int KPT>
 __global__ void __launch_bounds__(THREADS)
 route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_t kc, uint32_t *cand_pos,
                            uint32_t cstride, float *cand_max) {
@@ -953,19 +950,19 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
     __shared__ uint32_t wred[2 * (THREADS / 64)];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const float *fd = fdist + (uint64_t)q * fstride;
-    uint32_t keys[kPrefKpt];
+    uint32_t keys[KPT];
 #pragma unroll
-    for (int t = 0; t < kPrefKpt; ++t) {
+    for (int t = 0; t < KPT; ++t) {
         const uint32_t i = t * THREADS + tid;
         keys[t] = i < n ? f32_key(fd[i]) : 0xFFFFFFFFu;
     }
     if (tid < 2) misc[2 + tid] = 0; // winner counters (visible after the barriers inside the select)
     uint32_t want;
-    const uint32_t prefix = reg_radix_select<THREADS, kPrefKpt>(keys, n, kc, hist, wred, want);
+    const uint32_t prefix = reg_radix_select<THREADS, KPT>(keys, n, kc, hist, wred, want);
     const uint32_t T = prefix, budget = want, n_lt = kc - budget;
     uint32_t *cp = cand_pos + (uint64_t)q * cstride;
 #pragma unroll
-    for (int t = 0; t < kPrefKpt; ++t) {
+    for (int t = 0; t < KPT; ++t) {
         const uint32_t i = t * THREADS + tid;
         if (i < n) {
             if (keys[t] < T) {
