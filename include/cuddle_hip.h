@@ -208,6 +208,22 @@ cuddle_status cuddle_route_batch(cuddle_index *idx, const float *queries, uint32
                                  uint32_t dim, uint32_t probes_per_level, uint32_t flags,
                                  uint32_t *out_leaves, uint32_t leaf_stride,
                                  uint32_t *out_leaf_count);
+/* ---- index-build side --------------------------------------------------------------------- */
+/* KMeans::assign (src/clustering/kmeans.rs:136-160; nearest_centroid, :229-236, is the one-vector
+ * case): for each of n vectors the index of the nearest of k centroids under distance(metric)
+ * (src/distance/mod.rs:23-34) and that distance; equal minima go to the lowest index, as
+ * Iterator::min_by does. The n x k matrix is evaluated approximately on the matrix cores and
+ * exactly only where the approximation's error bound leaves a choice, so the result is the
+ * reference's bit for bit. All pointers are device memory: d_vectors [n][dim], d_centroids
+ * [k][dim], d_assign [n], d_dist [n]. *out_fallbacks (host, may be NULL) receives the number of
+ * (vector, 256-centroid segment) pairs that had to be compared exactly in full (three or more
+ * near-tied candidates in one segment, e.g. duplicate centroids).
+ * Allocates its workspace per call and returns after the work on `stream` has finished. */
+cuddle_status cuddle_kmeans_assign(const float *d_vectors, uint64_t n, const float *d_centroids,
+                                   uint32_t k, uint32_t dim, uint32_t metric, uint32_t *d_assign,
+                                   float *d_dist, uint64_t *out_fallbacks, int device_id,
+                                   void *stream);
+
 /* Diagnostic of the matrix-core routing filter (no counterpart in the reference, whose routing
  * at hierarchical.rs:355-391 evaluates every distance exactly; here a level as wide as a whole
  * frontier is first ranked by approximate distances, and the selection is accepted only where an

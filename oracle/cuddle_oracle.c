@@ -147,6 +147,27 @@ void orc_distance_pairs(const float *a, const float *b, uint64_t n, uint32_t dim
     for (uint64_t i = 0; i < n; ++i) out[i] = orc_distance(a + i * dim, b + i * dim, dim, metric);
 }
 
+/* KMeans::assign, src/clustering/kmeans.rs:136-160 (nearest_centroid, :229-236, is the same per
+ * vector): distance(v, c, metric) against every centroid in order; Iterator::min_by keeps the first
+ * of equal minima. */
+void orc_kmeans_assign(const float *vectors, uint64_t n, const float *centroids, uint32_t k, uint32_t dim,
+                       int metric, uint32_t *assign, float *dist) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        uint32_t best = 0;
+        float bd = orc_distance(vectors + (uint64_t)i * dim, centroids, dim, metric);
+        for (uint32_t c = 1; c < k; ++c) {
+            float d = orc_distance(vectors + (uint64_t)i * dim, centroids + (uint64_t)c * dim, dim, metric);
+            if (d < bd) {
+                bd = d;
+                best = c;
+            }
+        }
+        assign[i] = best;
+        dist[i] = bd;
+    }
+}
+
 /* ---------------------------------------------------------------------------------------- */
 /* src/quantization/binary.rs                                                                */
 /* ---------------------------------------------------------------------------------------- */

@@ -57,6 +57,7 @@ def lib() -> C.CDLL:
             "orc_l2_batch_rows": (None, [vp, vp, C.c_size_t, C.c_size_t, vp]),
             "orc_distance": (f32, [vp, vp, C.c_size_t, C.c_int]),
             "orc_distance_pairs": (None, [vp, vp, u64, u32, C.c_int, vp]),
+            "orc_kmeans_assign": (None, [vp, u64, vp, u32, u32, C.c_int, vp, vp]),
             "orc_binary_quantize": (None, [vp, u64, u32, f32, vp]),
             "orc_binary_threshold": (f32, [vp, u64, u32]),
             "orc_hamming": (u32, [vp, vp, u32]),
@@ -114,6 +115,15 @@ def distance_pairs(a, b, metric: int) -> np.ndarray:
     out = np.zeros(a.shape[0], dtype=np.float32)
     lib().orc_distance_pairs(_p(a), _p(b), a.shape[0], a.shape[1], metric, _p(out))
     return out
+
+
+def kmeans_assign(vectors, centroids, metric: int):
+    """KMeans::assign (kmeans.rs:136-160): (index of the nearest centroid, its distance) per vector."""
+    v, c = _f32(vectors), _f32(centroids)
+    assign = np.zeros(v.shape[0], dtype=np.uint32)
+    dist = np.zeros(v.shape[0], dtype=np.float32)
+    lib().orc_kmeans_assign(_p(v), v.shape[0], _p(c), c.shape[0], v.shape[1], metric, _p(assign), _p(dist))
+    return assign, dist
 
 
 def binary_quantize(v, threshold: float) -> np.ndarray:

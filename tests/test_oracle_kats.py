@@ -216,3 +216,29 @@ def test_error_codes():
     q = np.zeros(8, np.float32)
     q[0] = np.nan
     assert oi.search(q, 5, 1, 3)["rc"] == orc.ORC_ERR_NAN
+
+
+def test_kmeans_nearest_centroid():  # kmeans.rs:295-310 with the two centroids a converged fit gives
+    cent = np.array([[0.5, 0.5], [10.0, 10.0]], dtype=np.float32)
+    a, d = orc.kmeans_assign(np.array([[0.5, 0.5]], dtype=np.float32), cent, _ffi.METRIC_L2)
+    assert a[0] == 0 and d[0] == 0.0
+    pts = np.array([[1.0, 0.0], [0.0, 1.0], [10.0, 10.0]], dtype=np.float32)
+    a, d = orc.kmeans_assign(pts, cent, _ffi.METRIC_L2)
+    assert list(a) == [0, 0, 1] and list(d) == [0.5, 0.5, 0.0]
+
+
+def test_kmeans_assign_two_clusters_and_first_minimum():  # kmeans.rs:256-292; min_by keeps the first of equal minima
+    rng = np.random.default_rng(0)
+    pts = np.concatenate([rng.random((10, 2)) * 0.5, 10.0 + rng.random((10, 2)) * 0.5]).astype(np.float32)
+    cent = np.array([[0.25, 0.25], [10.25, 10.25]], dtype=np.float32)
+    a, _ = orc.kmeans_assign(pts, cent, _ffi.METRIC_L2)
+    assert list(a) == [0] * 10 + [1] * 10
+    dup = np.array([[1.0, 1.0], [3.0, 3.0], [1.0, 1.0]], dtype=np.float32)  # centroid 2 duplicates centroid 0
+    a, d = orc.kmeans_assign(np.array([[1.0, 1.5], [2.0, 2.0]], dtype=np.float32), dup, _ffi.METRIC_L2)
+    assert list(a) == [0, 0] and list(d) == [0.25, 2.0]
+    for metric in (_ffi.METRIC_L2, _ffi.METRIC_COSINE, _ffi.METRIC_DOT):  # agrees with distance() pair by pair
+        x = rng.standard_normal((50, 37)).astype(np.float32)
+        c = rng.standard_normal((9, 37)).astype(np.float32)
+        a, d = orc.kmeans_assign(x, c, metric)
+        full = np.stack([orc.distance_pairs(x, np.repeat(c[j:j + 1], 50, 0), metric) for j in range(9)], 1)
+        assert np.array_equal(a, full.argmin(1)) and np.array_equal(d, full.min(1))

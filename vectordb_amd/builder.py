@@ -40,7 +40,30 @@ def _pairwise(x: torch.Tensor, c: torch.Tensor, metric: int) -> torch.Tensor:
     return (x * x).sum(1, keepdim=True) + (c * c).sum(1)[None, :] - 2.0 * dots
 
 
+def kmeans_assign(x: torch.Tensor, c: torch.Tensor, metric, stream=None):
+    """KMeans::assign (kmeans.rs:136-160) on the GPU through the C ABI (cuddle_kmeans_assign): for
+    CUDA tensors x [n, d] and c [k, d] returns (assignment int32 [n], distance f32 [n], number of
+    vectors that needed the all-centroids exact comparison). Exact: distance() in the reference's
+    arithmetic, first of equal minima."""
+    if not (x.is_cuda and c.is_cuda):
+        raise ValueError("kmeans_assign runs on the GPU: pass CUDA tensors")
+    x = x.contiguous().float()
+    c = c.contiguous().float()
+    if x.shape[1] != c.shape[1]:
+        raise ValueError("dimension mismatch")
+    assign = torch.empty(x.shape[0], dtype=torch.int32, device=x.device)
+    dist = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    fb = np.zeros(1, dtype=np.uint64)
+    st = stream if stream is not None else torch.cuda.current_stream(x.device)
+    _ffi.check(_ffi.lib().cuddle_kmeans_assign(x.data_ptr(), x.shape[0], c.data_ptr(), c.shape[0], x.shape[1],
+                                               metric_id(metric), assign.data_ptr(), dist.data_ptr(), _ffi.ptr(fb),
+                                               x.device.index or 0, st.cuda_stream))
+    return assign, dist, int(fb[0])
+
+
 def _assign(x: torch.Tensor, c: torch.Tensor, metric: int, chunk: int = 262144) -> torch.Tensor:
+    if x.is_cuda:  # native exact assignment; a missing library is an error, not a fallback
+        return kmeans_assign(x, c, metric)[0].long()
     out = torch.empty(x.shape[0], dtype=torch.long, device=x.device)
     for s in range(0, x.shape[0], chunk):
         out[s:s + chunk] = _pairwise(x[s:s + chunk], c, metric).argmin(dim=1)

@@ -19,6 +19,7 @@
 #include "cuddle_route.hpp"
 #include "cuddle_shard.hpp"
 #include "cuddle_rabitq.hpp"
+#include "cuddle_build.hpp"
 
 using namespace cuddle;
 
@@ -1249,6 +1250,91 @@ extern "C" cuddle_status cuddle_route_filter_error(cuddle_index *idx, const floa
     st = body();
     (void)hipFree(d_max);
     return st;
+}
+
+// ---------------------------------------------------------------------------------------------
+// index-build side
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct DevBufs { // device allocations of one call, freed on every exit path
+    std::vector<void *> p;
+    ~DevBufs() { for (void *q : p) (void)hipFree(q); }
+    template <class T> cuddle_status alloc(size_t count, T **out) {
+        void *q = nullptr;
+        HIP_TRY(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+        p.push_back(q);
+        *out = (T *)q;
+        return CUDDLE_OK;
+    }
+};
+} // namespace
+
+extern "C" cuddle_status cuddle_kmeans_assign(const float *d_vectors, uint64_t n, const float *d_centroids, uint32_t k,
+                                              uint32_t dim, uint32_t metric, uint32_t *d_assign, float *d_dist,
+                                              uint64_t *out_fallbacks, int device_id, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_vectors || !d_centroids || !d_assign || !d_dist) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    if (dim == 0 || k == 0) return fail(CUDDLE_ERR_BAD_ARG, "dim and k must be >= 1");
+    if (metric > CUDDLE_METRIC_DOT) return fail(CUDDLE_ERR_BAD_ARG, "unknown metric %u", metric);
+    ST_TRY(use_device(device_id));
+    if (out_fallbacks) *out_fallbacks = 0;
+    if (n == 0) return CUDDLE_OK;
+    const uint32_t kp = split_kp(dim);
+    const uint32_t rows_max = (uint32_t)std::min<uint64_t>(n, 1u << 18); // vectors per pass
+    const uint32_t gx = (k + 63) / 64;
+    DevBufs bufs;
+    float *mu, *csq, *asq;
+    uint16_t *table, *asplit;
+    uint4 *best;
+    uint32_t *d_fb;
+    ST_TRY(bufs.alloc((size_t)dim, &mu));
+    ST_TRY(bufs.alloc((size_t)k, &csq));
+    ST_TRY(bufs.alloc((size_t)k * kp * 2, &table));
+    ST_TRY(bufs.alloc((size_t)rows_max * kp * 2, &asplit));
+    ST_TRY(bufs.alloc((size_t)rows_max, &asq));
+    ST_TRY(bufs.alloc((size_t)1, &d_fb));
+    HIP_TRY(hipMemsetAsync(mu, 0, dim * sizeof(float), stream));
+    HIP_TRY(hipMemsetAsync(d_fb, 0, sizeof(uint32_t), stream));
+    if (metric == CUDDLE_METRIC_L2) { // centre on the mean centroid: smaller norms, tighter error bound
+        double *acc;
+        ST_TRY(bufs.alloc((size_t)dim, &acc));
+        HIP_TRY(hipMemsetAsync(acc, 0, dim * sizeof(double), stream));
+        hipLaunchKernelGGL(level_sum_kernel, dim3((dim + 63) / 64, 256), dim3(64), 0, stream, d_centroids, (const uint32_t *)nullptr, k, dim, acc);
+        hipLaunchKernelGGL(level_mean_kernel, dim3((dim + 255) / 256), dim3(256), 0, stream, acc, k, dim, mu);
+    }
+    hipLaunchKernelGGL(level_table_kernel, dim3((k + 127) / 128), dim3(128), 0, stream, d_centroids, (const uint32_t *)nullptr, k, dim, kp, mu,
+                       table, csq);
+    std::vector<float> h(k);
+    HIP_TRY(hipMemcpyAsync(h.data(), csq, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float max_csq = 0.f;
+    for (float x : h) max_csq = std::max(max_csq, x);
+    // column segments of at most kAssignMaxTilesPerSeg tiles, fewer when the grid would not fill the device
+    const uint32_t gy_max = (rows_max + kGemmBM - 1) / kGemmBM;
+    uint32_t tiles_per_seg = std::min(kAssignMaxTilesPerSeg, gx);
+    while (tiles_per_seg > 1 && (uint64_t)gy_max * ((gx + tiles_per_seg - 1) / tiles_per_seg) < 2048) --tiles_per_seg;
+    const uint32_t cs = (gx + tiles_per_seg - 1) / tiles_per_seg;
+    ST_TRY(bufs.alloc((size_t)rows_max * cs * 2, &best));
+    for (uint64_t r0 = 0; r0 < n; r0 += rows_max) {
+        const uint32_t rows = (uint32_t)std::min<uint64_t>(rows_max, n - r0);
+        const float *vsrc = d_vectors + r0 * dim;
+        hipLaunchKernelGGL(center_queries_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, vsrc, mu, rows, dim, kp, asplit, asq);
+        const uint32_t gy = (rows + kGemmBM - 1) / kGemmBM;
+        if (kp >= 512)
+            hipLaunchKernelGGL(assign_gemm_kernel<64>, dim3(gy * cs), dim3(256), assign_gemm_lds_bytes<64>(), stream, (const u32x4 *)asplit,
+                               asq, (const u32x4 *)table, csq, rows, k, kp, metric, best, cs, tiles_per_seg);
+        else
+            hipLaunchKernelGGL(assign_gemm_kernel<32>, dim3(gy * cs), dim3(256), assign_gemm_lds_bytes<32>(), stream, (const u32x4 *)asplit,
+                               asq, (const u32x4 *)table, csq, rows, k, kp, metric, best, cs, tiles_per_seg);
+        hipLaunchKernelGGL(assign_finish_kernel, dim3((rows + 63) / 64), dim3(256), 0, stream, vsrc, d_centroids, rows, k, dim, metric, best,
+                           cs, tiles_per_seg, asq, max_csq, d_assign + r0, d_dist + r0, d_fb);
+        HIP_TRY(hipGetLastError());
+    }
+    uint32_t fb = 0;
+    HIP_TRY(hipMemcpyAsync(&fb, d_fb, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream)); // the workspace is freed on return
+    if (out_fallbacks) *out_fallbacks = fb;
+    return CUDDLE_OK;
 }
 
 // Uploads caller-given leaf lists of one chunk into the plan's leaf buffers.

@@ -664,13 +664,13 @@ __global__ void pos_leaf_kernel(const uint32_t *vec_off, uint32_t n_nodes, uint6
     pos_leaf[p] = lo;
 }
 
-// acc[i] += sum over this block's slice of the listed nodes of centroid[node][i] (double);
-// grid = (ceil(dim/64), slices), block = 64.
+// acc[i] += sum over this block's slice of the listed nodes (nodes == null: rows 0..n) of
+// centroid[node][i] (double); grid = (ceil(dim/64), slices), block = 64.
 __global__ void level_sum_kernel(const float *centroids, const uint32_t *nodes, uint32_t n, uint32_t dim, double *acc) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= dim) return;
     double s = 0.0;
-    for (uint32_t j = blockIdx.y; j < n; j += gridDim.y) s += (double)centroids[(uint64_t)nodes[j] * dim + i];
+    for (uint32_t j = blockIdx.y; j < n; j += gridDim.y) s += (double)centroids[(uint64_t)(nodes ? nodes[j] : j) * dim + i];
     atomicAdd(&acc[i], s);
 }
 __global__ void level_mean_kernel(const double *acc, uint32_t n, uint32_t dim, float *mu) {

@@ -716,12 +716,13 @@ __device__ __forceinline__ void bf16_split_store(uint16_t *row, uint32_t i, floa
 // the j-th node of the level (breadth-first order = the frontier order every query sees when all
 // earlier levels keep all their nodes) minus mu (L2: the level's mean centroid, which keeps the norms
 // and so the rounding error of the norm expansion small; other metrics: mu = 0), plus the squared
-// norm of the f32 row as a fused-multiply-add chain. One thread per row.
+// norm of the f32 row as a fused-multiply-add chain. One thread per row. level_nodes == null: row j
+// of `centroids` itself.
 __global__ void level_table_kernel(const float *centroids, const uint32_t *level_nodes, uint32_t n, uint32_t dim,
                                          uint32_t kp, const float *mu, uint16_t *table, float *sqn) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const float *c = centroids + (uint64_t)level_nodes[j] * dim;
+    const float *c = centroids + (uint64_t)(level_nodes ? level_nodes[j] : j) * dim;
     uint16_t *t = table + (uint64_t)j * kp * 2;
     float s = 0.f;
     for (uint32_t i = 0; i < dim; ++i) {
@@ -774,18 +775,16 @@ constexpr size_t route_gemm_lds_bytes() { return (size_t)(kGemmBM + 64 * NT) * (
 // host picks rg so that they take at most half of it) against its panel group's column panels of
 // B, the row tiles of one panel running together so that the panel is fetched once.
 // out: [M][ostride]. grid = 8 * ceil(gy / rg) * ceil(gx / (8 / rg)).
+// One block tile of the contraction: acc + cor = A[by tile] * B[bx tile]^T (see route_gemm_kernel for
+// the layouts). smem: route_gemm_lds_bytes<NT, BK>() bytes; starts with a barrier, so the caller may
+// have used the LDS for something else before. All 256 threads call.
 template <int NT, int BK>
-__global__ void __launch_bounds__(256, NT == 1 ? 3 : 2)
-route_gemm_kernel(const u32x4 *A, const float *Asq, const u32x4 *B, const float *Bsq, uint32_t M, uint32_t N,
-                        uint32_t kp, uint32_t metric, float *out, uint32_t ostride, uint32_t gx, uint32_t gy, uint32_t rg) {
+__device__ __forceinline__ void split_gemm_tile(const u32x4 *A, const u32x4 *B, uint32_t M, uint32_t N, uint32_t kp,
+                                                uint32_t by, uint32_t bx, unsigned char *smem, f32x16 (&acc)[2][NT],
+                                                f32x16 (&cor)[2][NT]) {
     constexpr int BN = 64 * NT, CH = BK / 4, RS = CH + 1, RPP = 256 / CH, PA = kGemmBM / RPP, PB = BN / RPP;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *As = reinterpret_cast<u32x4 *>(smem); // [128][RS]
     u32x4 *Bs = As + kGemmBM * RS;               // [BN][RS]
-    const uint32_t id = blockIdx.x;
-    const uint32_t xcd = id & 7, local = id >> 3, pgroups = 8 / rg, rows_per = (gy + rg - 1) / rg;
-    const uint32_t by = (xcd % rg) * rows_per + local % rows_per, bx = (local / rows_per) * pgroups + xcd / rg;
-    if (bx >= gx || by >= gy) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t wr = w >> 1, wc = w & 1, r = lane & 31, h = lane >> 5;
     const uint32_t lr = tid / CH, c = tid % CH, rowu = kp / 4; // 16-byte units per split row
@@ -807,7 +806,6 @@ route_gemm_kernel(const u32x4 *A, const float *Asq, const u32x4 *B, const float 
 #pragma unroll
         for (int i = 0; i < PB; ++i) Bs[(lr + RPP * i) * RS + c] = pb[i];
     };
-    f32x16 acc[2][NT], cor[2][NT];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -853,6 +851,29 @@ route_gemm_kernel(const u32x4 *A, const float *Asq, const u32x4 *B, const float 
                     cor[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], cor[mt][nt], 0, 0, 0);
         }
     }
+}
+
+// d~ of one (query row, node) from the contraction's S and the two squared norms.
+__device__ __forceinline__ float approx_distance(uint32_t metric, float s, float as, float bs) {
+    if (metric == kMetricL2) return __builtin_fmaf(-2.0f, s, as + bs);
+    if (metric == kMetricDot) return -s;
+    return 1.0f - s / (sqrtf(as) * sqrtf(bs));
+}
+
+template <int NT, int BK>
+__global__ void __launch_bounds__(256, NT == 1 ? 3 : 2)
+route_gemm_kernel(const u32x4 *A, const float *Asq, const u32x4 *B, const float *Bsq, uint32_t M, uint32_t N,
+                  uint32_t kp, uint32_t metric, float *out, uint32_t ostride, uint32_t gx, uint32_t gy, uint32_t rg) {
+    constexpr int BN = 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t id = blockIdx.x;
+    const uint32_t xcd = id & 7, local = id >> 3, pgroups = 8 / rg, rows_per = (gy + rg - 1) / rg;
+    const uint32_t by = (xcd % rg) * rows_per + local % rows_per, bx = (local / rows_per) * pgroups + xcd / rg;
+    if (bx >= gx || by >= gy) return;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t wr = w >> 1, wc = w & 1, r = lane & 31, h = lane >> 5;
+    f32x16 acc[2][NT], cor[2][NT];
+    split_gemm_tile<NT, BK>(A, B, M, N, kp, by, bx, smem, acc, cor);
     // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -865,12 +886,7 @@ route_gemm_kernel(const u32x4 *A, const float *Asq, const u32x4 *B, const float 
             for (int e = 0; e < 16; ++e) {
                 const uint32_t gm = by * kGemmBM + wr * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (gm >= M) continue;
-                const float s = acc[mt][nt][e] + cor[mt][nt][e], as = Asq[gm];
-                float d;
-                if (metric == kMetricL2) d = __builtin_fmaf(-2.0f, s, as + bs);
-                else if (metric == kMetricDot) d = -s;
-                else d = 1.0f - s / (sqrtf(as) * sqrtf(bs));
-                out[(uint64_t)gm * ostride + gn] = d;
+                out[(uint64_t)gm * ostride + gn] = approx_distance(metric, acc[mt][nt][e] + cor[mt][nt][e], Asq[gm], bs);
             }
         }
 }
