@@ -127,9 +127,20 @@ def cpu_baseline(fi, queries_np, k, probes, rf, budget_s=12.0):
         rc, ids, _, _ = oi.search_batch(queries_np[:sample], k, probes, rf, 0, threads)
         dt += time.perf_counter() - t0
         passes += 1
+    # the reference's own shape: one search() after another, parallel inside (about 3 s of it)
+    n_seq = int(max(8, min(sample, 3.0 / max(per_q / threads, 1e-9) / 4)))
+    t0 = time.perf_counter()
+    _, ids_seq, _, _ = oi.search_sequential(queries_np[:n_seq], k, probes, rf, 0, threads)
+    dt_seq = time.perf_counter() - t0
     return dict(value=sample * passes / dt, unit="queries/s", cores=threads, kind="port",
                 sample=f"{sample} of the {queries_np.shape[0]} benchmark queries x {passes} passes, same index and parameters, "
-                       f"{dt:.1f} s wall, oracle/cuddle_oracle.c with OpenMP (one query per thread)"), ids, sample
+                       f"{dt:.1f} s wall, oracle/cuddle_oracle.c with OpenMP (one query per thread)",
+                reference_shaped=dict(value=n_seq / dt_seq, unit="queries/s", cores=threads,
+                                      mean_latency_ms=dt_seq / n_seq * 1e3,
+                                      identical_to_batch_parallel=bool(np.array_equal(ids_seq, ids[:n_seq])),
+                                      sample=f"{n_seq} queries issued one after another, each search() spreading its routing "
+                                             f"(> 100 nodes), code scan and rerank loops over the {threads} threads, as the "
+                                             f"reference's rayon calls do")), ids, sample
 
 
 def main():

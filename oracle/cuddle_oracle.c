@@ -386,7 +386,10 @@ static int orc_route_impl(const cuddle_index_desc *d, const float *q, uint32_t p
             orc_l2_batch(q, rows, ncur, dim, bd);
             for (uint32_t i = 0; i < ncur; ++i) nd[i].d = bd[i];
         } else {
-            for (uint32_t i = 0; i < ncur; ++i)
+            /* the reference splits this loop over its thread pool when the frontier exceeds 100 nodes (:355-365);
+             * a no-op inside the one-query-per-thread batch driver (nested regions stay serial) */
+#pragma omp parallel for schedule(static) if (ncur > 100)
+            for (int64_t i = 0; i < (int64_t)ncur; ++i)
                 nd[i].d = orc_distance(q, d->centroids + (uint64_t)cur[i] * dim, dim, (int)d->metric);
         }
         for (uint32_t i = 0; i < ncur; ++i) { nd[i].node = cur[i]; nd[i].pos = i; }
@@ -449,7 +452,9 @@ static int orc_search_leaves_impl(const cuddle_index_desc *d, const float *q, co
         uint32_t words = (dim + 63) / 64;
         uint64_t *qc = (uint64_t *)malloc(sizeof(uint64_t) * words);
         orc_binary_quantize(q, 1, dim, d->threshold, qc); /* hierarchical.rs:340 */
-        for (uint64_t i = 0; i < n; ++i) c[i].key = orc_hamming(qc, d->codes + c[i].pos * words, words);
+        /* per-leaf tasks, and per-vector ones in leaves of more than 100 vectors, in the reference (:591-641) */
+#pragma omp parallel for schedule(static) if (n > 100)
+        for (int64_t i = 0; i < (int64_t)n; ++i) c[i].key = orc_hamming(qc, d->codes + c[i].pos * words, words);
         free(qc);
     } else {
         uint64_t *pos = (uint64_t *)malloc(sizeof(uint64_t) * n);
@@ -474,11 +479,14 @@ static int orc_search_leaves_impl(const cuddle_index_desc *d, const float *q, co
     qsort(c, n, sizeof(orc_cand), d->code_kind == CUDDLE_CODE_BINARY ? orc_cand_cmp_u32 : orc_cand_cmp_f32);
     uint64_t nsel = n < rerank_k ? n : rerank_k;
     /* rerank_with_full_precision, hierarchical.rs:659-674 */
-    for (uint64_t i = 0; i < nsel; ++i) {
-        c[i].order = i; /* phase-1 order */
+    int nan_seen = 0; /* the reference reranks with par_iter (:659-674) */
+#pragma omp parallel for schedule(static) reduction(| : nan_seen) if (nsel > 100)
+    for (int64_t i = 0; i < (int64_t)nsel; ++i) {
+        c[i].order = (uint64_t)i; /* phase-1 order */
         c[i].dist = orc_distance(q, d->vectors + c[i].pos * dim, dim, (int)d->metric);
-        if (c[i].dist != c[i].dist) rc = ORC_ERR_NAN;
+        if (c[i].dist != c[i].dist) nan_seen = 1;
     }
+    if (nan_seen) rc = ORC_ERR_NAN;
     if (tr) {
         tr->n_sel = nsel;
         for (uint64_t i = 0; i < nsel && i < tr->sel_cap; ++i) {
@@ -557,6 +565,25 @@ int orc_search_batch(const cuddle_index_desc *d, const float *queries, uint32_t 
 #endif
             { if (rc_all == ORC_OK) rc_all = rc; }
         }
+    }
+    return rc_all;
+}
+
+/* The reference's shape: search() calls issued one after another, each spreading its routing, scan
+ * and rerank loops over the thread pool (the parallel regions inside orc_search). */
+int orc_search_sequential(const cuddle_index_desc *d, const float *queries, uint32_t n_queries, uint32_t dim,
+                          uint32_t k, uint32_t probes, uint32_t rerank_factor, uint32_t flags, uint64_t *out_ids,
+                          float *out_dist, uint32_t *out_count, int n_threads) {
+    int rc_all = ORC_OK;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    for (uint32_t qi = 0; qi < n_queries; ++qi) {
+        uint32_t cnt = 0;
+        int rc = orc_search(d, queries + (uint64_t)qi * dim, dim, k, probes, rerank_factor, flags,
+                            out_ids + (uint64_t)qi * k, out_dist + (uint64_t)qi * k, &cnt, NULL);
+        if (out_count) out_count[qi] = cnt;
+        if (rc != ORC_OK && rc_all == ORC_OK) rc_all = rc;
     }
     return rc_all;
 }

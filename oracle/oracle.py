@@ -70,6 +70,7 @@ def lib() -> C.CDLL:
             "orc_search": (C.c_int, [C.POINTER(_ffi.IndexDesc), vp, u32, u32, u32, u32, u32, vp, vp, vp, C.POINTER(Trace)]),
             "orc_search_leaves": (C.c_int, [C.POINTER(_ffi.IndexDesc), vp, vp, u32, u32, u32, u32, vp, vp, vp, C.POINTER(Trace)]),
             "orc_search_batch": (C.c_int, [C.POINTER(_ffi.IndexDesc), vp, u32, u32, u32, u32, u32, u32, vp, vp, vp, C.c_int]),
+            "orc_search_sequential": (C.c_int, [C.POINTER(_ffi.IndexDesc), vp, u32, u32, u32, u32, u32, u32, vp, vp, vp, C.c_int]),
             "orc_num_threads": (C.c_int, []),
         }
         for name, (res, args) in sig.items():
@@ -231,6 +232,17 @@ class OracleIndex:
         cnt = np.zeros(nq, dtype=np.uint32)
         rc = lib().orc_search_batch(C.byref(self.desc), _p(q), nq, dim, k, probes, rerank_factor, flags, _p(ids),
                                     _p(dist), _p(cnt), n_threads)
+        return rc, ids, dist, cnt
+
+    def search_sequential(self, queries, k: int, probes: int, rerank_factor: int, flags: int = 0, n_threads: int = 0):
+        """One search() after another, each using the thread pool inside (the reference's own shape)."""
+        q = _f32(queries)
+        nq, dim = q.shape
+        ids = np.zeros((nq, k), dtype=np.uint64)
+        dist = np.zeros((nq, k), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        rc = lib().orc_search_sequential(C.byref(self.desc), _p(q), nq, dim, k, probes, rerank_factor, flags, _p(ids),
+                                         _p(dist), _p(cnt), n_threads)
         return rc, ids, dist, cnt
 
 
