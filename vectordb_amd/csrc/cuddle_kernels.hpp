@@ -83,14 +83,36 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
     return (1ull << (threadIdx.x & 63)) - 1ull;
 }
 
-// Inclusive prefix sum across the 64 lanes of a wave.
+// Inclusive prefix sum across the 64 lanes of a wave (all 64 active), by DPP moves instead of the LDS
+// crossbar: row shifts 1/2/4/8 scan each 16-lane row, row_bcast 15 adds row 0's total to row 1 and
+// row 2's to row 3, row_bcast 31 adds the total of rows 0-1 to rows 2 and 3. Lanes without a source add 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_step(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o, 64);
-        if ((int)(threadIdx.x & 63) >= o) v += t;
-    }
+    v = dpp_add_step<0x111, 0xF>(v); // row_shr:1
+    v = dpp_add_step<0x112, 0xF>(v); // row_shr:2
+    v = dpp_add_step<0x114, 0xF>(v); // row_shr:4
+    v = dpp_add_step<0x118, 0xF>(v); // row_shr:8
+    v = dpp_add_step<0x142, 0xA>(v); // row_bcast:15
+    v = dpp_add_step<0x143, 0xC>(v); // row_bcast:31
     return v;
+}
+
+// Smallest u32 of the wave (all 64 lanes active), in every lane; same DPP sequence, identity ~0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_min_step_u32(uint32_t v) {
+    return min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = dpp_min_step_u32<0x111, 0xF>(v);
+    v = dpp_min_step_u32<0x112, 0xF>(v);
+    v = dpp_min_step_u32<0x114, 0xF>(v);
+    v = dpp_min_step_u32<0x118, 0xF>(v);
+    v = dpp_min_step_u32<0x142, 0xA>(v);
+    v = dpp_min_step_u32<0x143, 0xC>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // In-place exclusive prefix sum of lds[0..n) by the first wave of the block; lds[n] receives
@@ -1167,6 +1189,28 @@ topk_kernel(IndexDev ix, const uint32_t *sel_pos, const uint32_t *sel_key, const
     if (tid == 0 && out_count) out_count[q] = nout;
 }
 
+// Smallest u64 of the wave, in every lane, by DPP moves (no LDS crossbar): row shifts 1/2/4/8 leave
+// each 16-lane row's minimum in its last lane, row_bcast 15 / 31 carry it across the rows into lane
+// 63, a readlane broadcasts it. Lanes without a source keep the identity ~0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_min_step_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)v, CTRL, ROW_MASK, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xF, false);
+    const uint64_t o = ((uint64_t)hi << 32) | lo;
+    return o < v ? o : v;
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+    v = dpp_min_step_u64<0x111, 0xF>(v); // row_shr:1
+    v = dpp_min_step_u64<0x112, 0xF>(v); // row_shr:2
+    v = dpp_min_step_u64<0x114, 0xF>(v); // row_shr:4
+    v = dpp_min_step_u64<0x118, 0xF>(v); // row_shr:8
+    v = dpp_min_step_u64<0x142, 0xA>(v); // row_bcast:15 into rows 1 and 3
+    v = dpp_min_step_u64<0x143, 0xC>(v); // row_bcast:31 into rows 2 and 3
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // topk_kernel for k <= 64 and selections of at most 64 * KPL candidates: one WAVE per query (one
 // query per 64 threads of the block), the keys in registers (KPL per lane), k rounds of "smallest
 // key of the wave, its owner retires it". No LDS, no barrier. Same keys, same order.
@@ -1196,12 +1240,7 @@ topk_wave_kernel(IndexDev ix, const uint32_t *sel_pos, const uint32_t *sel_key, 
         uint64_t m = keys[0];
 #pragma unroll
         for (int t = 1; t < KPL; ++t) m = keys[t] < m ? keys[t] : m;
-        uint64_t wm = m;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint64_t other = (uint64_t)__shfl_xor((long long)wm, o, 64);
-            wm = other < wm ? other : wm;
-        }
+        const uint64_t wm = wave_min_u64(m);
         if (lane == r) mine = wm;
         if (m == wm) { // keys are distinct (the index is part of them): exactly one lane owns the minimum
 #pragma unroll

@@ -105,11 +105,8 @@ __device__ __forceinline__ uint32_t reg_radix_select(const uint32_t (&keys)[KPT]
             kmax = max(kmax, keys[t]);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
-        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
-    }
+    kmin = wave_min_u32(kmin);
+    kmax = ~wave_min_u32(~kmax);
     if (lane == 0) {
         wred[w] = kmin;
         wred[THREADS / 64 + w] = kmax;
