@@ -1041,14 +1041,14 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
                 uint64_t hit = __ballot(incl >= rerank_k);
                 if (hit) {
                     uint32_t first = __ffsll((unsigned long long)hit) - 1;
-                    uint32_t incl_f = __shfl(incl, first, 64), v_f = __shfl(v, first, 64);
+                    uint32_t incl_f = (uint32_t)__builtin_amdgcn_readlane((int)incl, first), v_f = (uint32_t)__builtin_amdgcn_readlane((int)v, first);
                     if (lane == 0) {
                         s.misc[0] = b0 + first;
                         s.misc[1] = rerank_k - (incl_f - v_f);
                     }
                     done = true;
                 }
-                carry = __shfl(incl, 63, 64);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
         __syncthreads();

@@ -145,8 +145,8 @@ __device__ __forceinline__ uint32_t reg_radix_select(const uint32_t (&keys)[KPT]
         if (cum + h0 < want) { cum += h0; ++b;
             if (cum + h1 < want) { cum += h1; ++b;
                 if (cum + h2 < want) { cum += h2; ++b; } } }
-        prefix |= (uint32_t)__shfl((int)b, first, 64) << shift;
-        want -= (uint32_t)__shfl((int)cum, first, 64);
+        prefix |= (uint32_t)__builtin_amdgcn_readlane((int)b, first) << shift;
+        want -= (uint32_t)__builtin_amdgcn_readlane((int)cum, first);
         rem = shift;
     }
     budget = want;

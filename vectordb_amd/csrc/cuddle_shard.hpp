@@ -45,12 +45,12 @@ shard_ties_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const u
             const uint64_t hit = __ballot(incl >= rerank_k);
             if (hit) {
                 const uint32_t first = __ffsll((unsigned long long)hit) - 1;
-                const uint32_t incl_f = __shfl(incl, first, 64), v_f = __shfl(v, first, 64);
+                const uint32_t incl_f = (uint32_t)__builtin_amdgcn_readlane((int)incl, first), v_f = (uint32_t)__builtin_amdgcn_readlane((int)v, first);
                 T = b0 + first;
                 budget = rerank_k - (incl_f - v_f);
                 done = true;
             }
-            carry = __shfl(incl, 63, 64);
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
         if (lane == 0) {
             s.misc[0] = T;
