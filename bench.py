@@ -239,19 +239,26 @@ def main():
         return dev_index.search_batch_device(q, kk, pp, rr, flags, out_ids, out_dist, out_cnt)
 
     class _ShardEngine:  # this rank's shard behind the three-step interface, stage timing on
-        def shard_scan(self, q, kk, pp, rr):
-            return dev_index.shard_scan(q, kk, pp, rr, flags)
+        def shard_scan(self, q, kk, pp, rr, leaves=None, leaf_count=None):
+            return dev_index.shard_scan(q, kk, pp, rr, flags, leaves=leaves, leaf_count=leaf_count)
+
+        def route_device(self, q, pp):
+            return dev_index.route_device(q, pp, flags)
 
         shard_ties = staticmethod(dev_index.shard_ties)
         shard_finish = staticmethod(dev_index.shard_finish)
 
     exact = world > 1 and args.sharded == "exact"
-    searcher = ExactShardedSearcher(_ShardEngine()) if exact else ShardedSearcher(local_search)
+    # CUDDLE_BENCH_SHARD_ROUTING=0: every rank routes the whole batch (A/B against routing a slice each + all-gather)
+    searcher = (ExactShardedSearcher(_ShardEngine(), shard_routing=os.environ.get("CUDDLE_BENCH_SHARD_ROUTING", "1") != "0")
+                if exact else ShardedSearcher(local_search))
 
     def step():
+        trace("step: search")
         out = searcher.search_batch(queries, k, probes, rf_box[0])
         if world > 1 and backend != "nccl":
             torch.cuda.synchronize()  # rehearsal backends stage CUDA tensors through the host on their own streams
+        trace("step: done")
         return out
 
     # ---- operating point: cheapest sweep point with recall@10 >= 0.95 ------------------------
@@ -276,6 +283,7 @@ def main():
     rf_box[0] = chosen
     trace(f"operating point rf={chosen}")
     dev_index.stage_times()  # drop the sweep's timings
+    trace("sweep timings dropped")
 
     # ---- timed region ---------------------------------------------------------------------------
     for _ in range(args.warmup):

@@ -236,6 +236,19 @@ cuddle_status cuddle_route_filter_error(cuddle_index *idx, const float *queries,
                                         uint32_t n_queries, uint32_t dim,
                                         uint32_t probes_per_level, uint32_t level,
                                         float *out_max_ratio, float *out_max_abs);
+/* The same on device pointers, enqueued on `stream` (1..4096 queries per call): d_leaves
+ * [n_queries][leaf_stride] and d_leaf_count [n_queries] receive the leaf lists. leaf_stride
+ * must be at least cuddle_index_leaf_stride(probes_per_level), the capacity every search with
+ * that probes_per_level uses for its leaf lists (it depends on the tree only). The lists are
+ * copied out of the handle's workspace asynchronously: the next call on the handle must use
+ * the same stream. */
+cuddle_status cuddle_index_leaf_stride(const cuddle_index *idx, uint32_t probes_per_level,
+                                       uint32_t *out);
+cuddle_status cuddle_route_batch_device(cuddle_index *idx, const float *d_queries,
+                                        uint32_t n_queries, uint32_t dim,
+                                        uint32_t probes_per_level, uint32_t flags,
+                                        uint32_t *d_leaves, uint32_t leaf_stride,
+                                        uint32_t *d_leaf_count, void *stream);
 /* collect_leaf_candidates (hierarchical.rs:618-641 / hierarchical_with_rabitq.rs:605-619)
  * for given leaf lists: per query the (position, code distance) pairs in scan order.
  * out_pos: [n_queries][cand_stride] leaf-contiguous positions (ids[pos] is the vector id);
@@ -289,6 +302,18 @@ cuddle_status cuddle_shard_scan(cuddle_index *idx, const float *d_queries, uint3
                                 uint32_t dim, uint32_t k, uint32_t probes_per_level,
                                 uint32_t rerank_factor, uint32_t flags, uint32_t *d_hist,
                                 uint32_t *leaf_stride, void *stream);
+/* Routing is the same on every shard (the tree is replicated), so the shards may split it by
+ * queries instead of repeating it: each routes a slice of the batch with
+ * cuddle_route_batch_device, the leaf lists are all-gathered, and every shard scans the whole
+ * batch with cuddle_shard_scan_leaves (cuddle_shard_scan with the routing replaced by the given
+ * lists: d_leaves [n_queries][leaf_stride_in] node ids in accumulation order, d_leaf_count
+ * [n_queries]; ids beyond the tree are clamped). */
+cuddle_status cuddle_shard_scan_leaves(cuddle_index *idx, const float *d_queries,
+                                       uint32_t n_queries, uint32_t dim, uint32_t k,
+                                       uint32_t probes_per_level, uint32_t rerank_factor,
+                                       uint32_t flags, const uint32_t *d_leaves,
+                                       uint32_t leaf_stride_in, const uint32_t *d_leaf_count,
+                                       uint32_t *d_hist, uint32_t *leaf_stride, void *stream);
 cuddle_status cuddle_shard_ties(cuddle_index *idx, const uint32_t *d_global_hist,
                                 uint32_t *d_tie_count, void *stream);
 cuddle_status cuddle_shard_finish(cuddle_index *idx, const float *d_queries,

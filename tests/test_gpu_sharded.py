@@ -24,11 +24,12 @@ def _check(fi, gpu, q, cases, worlds=(2, 3)):
         shards = [DeviceIndex(fi.shard(r, world), gpu) for r in range(world)]
         for (k, probes, rf) in cases:
             ids0, d0, c0 = full.search_batch_device(dq, k, probes, rf)
-            ids1, d1, c1 = exact_search_in_process(shards, dq, k, probes, rf)
-            torch.cuda.synchronize()
-            assert torch.equal(c0.cpu(), c1.cpu()), (world, k, probes, rf)
-            assert torch.equal(ids0.cpu(), ids1.cpu()), (world, k, probes, rf)
-            assert np.array_equal(_bits(d0.cpu().numpy()), _bits(d1.cpu().numpy())), (world, k, probes, rf)
+            for shard_routing in (False, True):  # every shard routes the batch / each routes a slice of it
+                ids1, d1, c1 = exact_search_in_process(shards, dq, k, probes, rf, shard_routing=shard_routing)
+                torch.cuda.synchronize()
+                assert torch.equal(c0.cpu(), c1.cpu()), (world, k, probes, rf, shard_routing)
+                assert torch.equal(ids0.cpu(), ids1.cpu()), (world, k, probes, rf, shard_routing)
+                assert np.array_equal(_bits(d0.cpu().numpy()), _bits(d1.cpu().numpy())), (world, k, probes, rf, shard_routing)
 
 
 @pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
@@ -62,3 +63,28 @@ def test_world_of_one_is_the_plain_search(gpu):
     torch.cuda.synchronize()
     assert torch.equal(ids0, ids1) and torch.equal(c0, c1)
     assert np.array_equal(_bits(d0.cpu().numpy()), _bits(d1.cpu().numpy()))
+
+
+def test_route_device_matches_host_entry_point(gpu):
+    from vectordb_amd import _ffi
+    import ctypes as C
+
+    x, fi = small_index(n=6000, d=48, n_clusters=40, branching=8, leaf=40)
+    dev = DeviceIndex(fi, gpu)
+    q = queries_like(x, 70, 3)
+    dq = torch.from_numpy(q).cuda(gpu)
+    for probes in (1, 4, 9, 1000):
+        lv_h, lc_h = dev.route_batch(q, probes)
+        lv_d, lc_d = dev.route_device(dq, probes)
+        torch.cuda.synchronize()
+        lv_d, lc_d = lv_d.cpu().numpy(), lc_d.cpu().numpy()
+        assert lv_d.shape[1] == dev.leaf_stride(probes)
+        assert np.array_equal(lc_h.astype(np.int32), lc_d)
+        for i in range(q.shape[0]):
+            assert np.array_equal(lv_h[i, :lc_h[i]].astype(np.int32), lv_d[i, :lc_d[i]]), (probes, i)
+    # a leaf buffer narrower than the plan's lists is refused
+    small = torch.zeros((70, 1), dtype=torch.int32, device=dq.device)
+    cnt = torch.zeros(70, dtype=torch.int32, device=dq.device)
+    st = dev._lib.cuddle_route_batch_device(dev._handle, C.c_void_p(dq.data_ptr()), 70, 48, 9, 0, C.c_void_p(small.data_ptr()), 1,
+                                            C.c_void_p(cnt.data_ptr()), None)
+    assert st == _ffi.ERR_BAD_ARG

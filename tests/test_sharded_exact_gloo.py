@@ -32,11 +32,28 @@ class OracleShardEngine:
         self.fi = flat_shard
         self.oi = orc.OracleIndex(flat_shard)
 
-    def shard_scan(self, queries, k, probes, rf):
+    def route_device(self, queries, probes):
+        """Routing of a slice of the batch: (leaves [n, stride], count [n]); the stride is a property of the tree."""
+        q = queries.numpy()
+        self.routed = q.shape[0]
+        leaves = np.zeros((q.shape[0], self.fi.n_nodes), dtype=np.int32)
+        count = np.zeros(q.shape[0], dtype=np.int32)
+        for i in range(q.shape[0]):
+            lv = self.oi.search(q[i], 1, probes, 1, trace=True)["leaves"]
+            leaves[i, :len(lv)] = lv
+            count[i] = len(lv)
+        return torch.from_numpy(leaves), torch.from_numpy(count)
+
+    def shard_scan(self, queries, k, probes, rf, leaves=None, leaf_count=None):
         q = queries.numpy()
         self.k, self.rerank_k = k, min(k * rf, 10000)
         D = self.fi.dim
         self.tr = [self.oi.search(q[i], k, probes, rf, trace=True) for i in range(q.shape[0])]
+        if leaves is not None:  # lists routed by the other ranks and all-gathered: they must be this rank's own routing
+            self.given = True
+            for i, t in enumerate(self.tr):
+                assert int(leaf_count[i]) == len(t["leaves"]), i
+                assert np.array_equal(leaves[i, :len(t["leaves"])].numpy().astype(np.uint32), t["leaves"]), i
         self.stride = max(len(t["leaves"]) for t in self.tr)
         hist = np.zeros((q.shape[0], D + 1), dtype=np.int32)
         for i, t in enumerate(self.tr):
@@ -109,11 +126,17 @@ def _worker(rank, world, port, out_path):
 
         x, fi = small_index(n=4000, d=16, n_clusters=20, branching=6, leaf=30)
         q = queries_like(x, 24, 9)
-        searcher = ExactShardedSearcher(OracleShardEngine(fi.shard(rank, world)))
-        assert searcher.world == world and searcher.rank == rank
+        engine = OracleShardEngine(fi.shard(rank, world))
+        searcher = ExactShardedSearcher(engine)
+        assert searcher.world == world and searcher.rank == rank and searcher.shard_routing
+        plain = ExactShardedSearcher(OracleShardEngine(fi.shard(rank, world)), shard_routing=False)
         res = {}
         for name, (k, probes, rf) in CASES.items():
             ids, dd, cnt = searcher.search_batch(torch.from_numpy(q), k, probes, rf)
+            per = (q.shape[0] + world - 1) // world
+            assert engine.given and engine.routed == max(0, min(per, q.shape[0] - rank * per))  # routed only its slice
+            ids2, dd2, cnt2 = plain.search_batch(torch.from_numpy(q), k, probes, rf)  # every rank routing everything
+            assert torch.equal(ids, ids2) and torch.equal(dd, dd2) and torch.equal(cnt, cnt2)
             res[name] = (ids.numpy().copy(), dd.numpy().copy(), cnt.numpy().copy())
             t = torch.from_numpy(res[name][0].copy())
             dist.broadcast(t, src=0)

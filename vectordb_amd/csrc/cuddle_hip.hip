@@ -1466,9 +1466,69 @@ extern "C" cuddle_status cuddle_search_leaves_batch(cuddle_index *idx, const flo
 // ---------------------------------------------------------------------------------------------
 // leaf-sharded exact search: cuddle_search_batch_device split where the shards must agree
 // ---------------------------------------------------------------------------------------------
-extern "C" cuddle_status cuddle_shard_scan(cuddle_index *idx, const float *d_queries, uint32_t n_queries, uint32_t dim,
-                                           uint32_t k, uint32_t probes_per_level, uint32_t rerank_factor, uint32_t flags,
-                                           uint32_t *d_hist, uint32_t *leaf_stride, void *stream) {
+// Leaf-list capacity a plan for this probes_per_level uses (make_plan's lstride; it does not depend on
+// the batch size or k).
+static uint32_t plan_leaf_stride(const cuddle_index *ix, uint32_t probes) {
+    probes = std::min(probes, kSortCap);
+    uint64_t fb = ix->dev.n_roots, lsum = 0;
+    for (uint32_t l = 0; l < ix->n_levels; ++l) {
+        fb = std::min<uint64_t>(fb, ix->level_width[l]);
+        const uint64_t sel = std::min<uint64_t>(fb, probes);
+        lsum += std::min<uint64_t>(sel, ix->level_leaves[l]);
+        fb = sel * std::max<uint32_t>(ix->max_children, 1);
+    }
+    return (uint32_t)align_up(std::max<uint64_t>(std::min<uint64_t>(lsum, ix->n_leaves), 1), 4);
+}
+
+extern "C" cuddle_status cuddle_index_leaf_stride(const cuddle_index *idx, uint32_t probes_per_level, uint32_t *out) {
+    if (!idx || !out) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+    if (probes_per_level == 0) return fail(CUDDLE_ERR_BAD_ARG, "probes_per_level must be >= 1");
+    *out = plan_leaf_stride(idx, probes_per_level);
+    return CUDDLE_OK;
+}
+
+// Caller-given leaf lists -> the plan's: out-of-range node ids are clamped (a non-leaf id scans nothing).
+__global__ void adopt_leaves_kernel(const uint32_t *src, uint32_t src_stride, const uint32_t *src_count, uint32_t nq,
+                                    uint32_t n_nodes, uint32_t *dst, uint32_t dst_stride, uint32_t *dst_count) {
+    const uint32_t q = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t n = min(src_count[q], min(src_stride, dst_stride));
+    if (i < n) dst[(uint64_t)q * dst_stride + i] = min(src[(uint64_t)q * src_stride + i], n_nodes - 1);
+    if (i == 0) dst_count[q] = n;
+}
+
+extern "C" cuddle_status cuddle_route_batch_device(cuddle_index *idx, const float *d_queries, uint32_t n_queries, uint32_t dim,
+                                                   uint32_t probes_per_level, uint32_t flags, uint32_t *d_leaves,
+                                                   uint32_t leaf_stride, uint32_t *d_leaf_count, void *stream) {
+    if (!idx || !d_queries || !d_leaves || !d_leaf_count) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    if (dim != idx->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, idx->dev.dim);
+    if (probes_per_level == 0) return fail(CUDDLE_ERR_BAD_ARG, "probes_per_level must be >= 1");
+    if (n_queries == 0) return CUDDLE_OK;
+    if (n_queries > kMaxChunk) return fail(CUDDLE_ERR_UNSUPPORTED, "1..%u queries per call", kMaxChunk);
+    if (leaf_stride < plan_leaf_stride(idx, probes_per_level))
+        return fail(CUDDLE_ERR_BAD_ARG, "leaf_stride %u < cuddle_index_leaf_stride() = %u", leaf_stride, plan_leaf_stride(idx, probes_per_level));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    idx->shard_state = 0;
+    idx->timed = (flags & CUDDLE_SEARCH_TIME_STAGES) != 0 && idx->events_used + 4096 < kMaxEvents;
+    idx->last_stream = s;
+    Plan &pl = idx->shard_plan; // held by the handle: the copies below are asynchronous
+    pl = Plan();
+    ST_TRY(make_plan(idx, n_queries, 1, probes_per_level, 1, 0, pl));
+    mark(idx, s, CUDDLE_STAGE_ROUTE);
+    ST_TRY(launch_route(idx, pl, d_queries, n_queries, flags, s));
+    HIP_TRY(hipMemcpy2DAsync(d_leaves, (size_t)leaf_stride * 4, pl.leaves, (size_t)pl.lstride * 4, (size_t)pl.lstride * 4, n_queries,
+                             hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_leaf_count, pl.lcount, (size_t)n_queries * 4, hipMemcpyDeviceToDevice, s));
+    mark(idx, s, -1);
+    return CUDDLE_OK;
+}
+
+static cuddle_status shard_scan_impl(cuddle_index *idx, const float *d_queries, uint32_t n_queries, uint32_t dim, uint32_t k,
+                                     uint32_t probes_per_level, uint32_t rerank_factor, uint32_t flags, const uint32_t *d_leaves,
+                                     uint32_t leaf_stride_in, const uint32_t *d_leaf_count, uint32_t *d_hist,
+                                     uint32_t *leaf_stride, void *stream) {
     if (!idx || !d_queries || !d_hist) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
     ST_TRY(use_device(idx->device));
@@ -1491,7 +1551,13 @@ extern "C" cuddle_status cuddle_shard_scan(cuddle_index *idx, const float *d_que
     mark(idx, s, CUDDLE_STAGE_QUANTIZE);
     ST_TRY(launch_quantize(idx, pl, d_queries, n_queries, s));
     mark(idx, s, CUDDLE_STAGE_ROUTE);
-    ST_TRY(launch_route(idx, pl, d_queries, n_queries, flags, s));
+    if (d_leaves) {
+        hipLaunchKernelGGL(adopt_leaves_kernel, dim3((pl.lstride + 255) / 256, n_queries), dim3(256), 0, s, d_leaves, leaf_stride_in,
+                           d_leaf_count, n_queries, idx->dev.n_nodes, pl.leaves, pl.lstride, pl.lcount);
+        HIP_TRY(hipGetLastError());
+    } else {
+        ST_TRY(launch_route(idx, pl, d_queries, n_queries, flags, s));
+    }
     mark(idx, s, CUDDLE_STAGE_SCAN);
     ST_TRY(launch_scan_select(idx, pl, n_queries, s, d_hist));
     mark(idx, s, -1);
@@ -1499,6 +1565,22 @@ extern "C" cuddle_status cuddle_shard_scan(cuddle_index *idx, const float *d_que
     idx->shard_state = 1;
     if (leaf_stride) *leaf_stride = pl.lstride;
     return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_shard_scan(cuddle_index *idx, const float *d_queries, uint32_t n_queries, uint32_t dim,
+                                           uint32_t k, uint32_t probes_per_level, uint32_t rerank_factor, uint32_t flags,
+                                           uint32_t *d_hist, uint32_t *leaf_stride, void *stream) {
+    return shard_scan_impl(idx, d_queries, n_queries, dim, k, probes_per_level, rerank_factor, flags, nullptr, 0, nullptr, d_hist,
+                           leaf_stride, stream);
+}
+
+extern "C" cuddle_status cuddle_shard_scan_leaves(cuddle_index *idx, const float *d_queries, uint32_t n_queries, uint32_t dim,
+                                                  uint32_t k, uint32_t probes_per_level, uint32_t rerank_factor, uint32_t flags,
+                                                  const uint32_t *d_leaves, uint32_t leaf_stride_in, const uint32_t *d_leaf_count,
+                                                  uint32_t *d_hist, uint32_t *leaf_stride, void *stream) {
+    if (!d_leaves || !d_leaf_count) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+    return shard_scan_impl(idx, d_queries, n_queries, dim, k, probes_per_level, rerank_factor, flags, d_leaves, leaf_stride_in,
+                           d_leaf_count, d_hist, leaf_stride, stream);
 }
 
 extern "C" cuddle_status cuddle_shard_ties(cuddle_index *idx, const uint32_t *d_global_hist, uint32_t *d_tie_count,

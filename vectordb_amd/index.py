@@ -115,7 +115,7 @@ class DeviceIndex:
 
     # ---- leaf-sharded exact search: the three steps between which the shards exchange counts ----
     def shard_scan(self, d_queries, k: int, probes_per_level: int, rerank_factor: int, flags: int = 0,
-                   stream: Optional[int] = None):
+                   stream: Optional[int] = None, leaves=None, leaf_count=None):
         """Step 1 on this shard: returns the shard's Hamming histogram, int32 CUDA tensor
         [nq, dim + 1], to be summed over the shards."""
         import torch
@@ -126,11 +126,43 @@ class DeviceIndex:
             stream = torch.cuda.current_stream(d_queries.device).cuda_stream
         hist = torch.empty((nq, dim + 1), dtype=torch.int32, device=d_queries.device)
         stride = C.c_uint32(0)
-        _ffi.check(self._lib.cuddle_shard_scan(self._handle, C.c_void_p(d_queries.data_ptr()), nq, dim, k, probes_per_level,
-                                               rerank_factor, flags, C.c_void_p(hist.data_ptr()), C.byref(stride),
-                                               C.c_void_p(stream)))
+        if leaves is None:
+            _ffi.check(self._lib.cuddle_shard_scan(self._handle, C.c_void_p(d_queries.data_ptr()), nq, dim, k, probes_per_level,
+                                                   rerank_factor, flags, C.c_void_p(hist.data_ptr()), C.byref(stride),
+                                                   C.c_void_p(stream)))
+        else:  # routing done elsewhere (route_device on slices of the batch, all-gathered)
+            assert leaves.is_cuda and leaves.dtype == torch.int32 and leaves.is_contiguous() and leaves.shape[0] == nq
+            assert leaf_count.is_cuda and leaf_count.dtype == torch.int32 and leaf_count.is_contiguous()
+            _ffi.check(self._lib.cuddle_shard_scan_leaves(self._handle, C.c_void_p(d_queries.data_ptr()), nq, dim, k,
+                                                          probes_per_level, rerank_factor, flags,
+                                                          C.c_void_p(leaves.data_ptr()), leaves.shape[1],
+                                                          C.c_void_p(leaf_count.data_ptr()), C.c_void_p(hist.data_ptr()),
+                                                          C.byref(stride), C.c_void_p(stream)))
         self._shard = (nq, k, int(stride.value))
         return hist
+
+    def leaf_stride(self, probes_per_level: int) -> int:
+        """Capacity of a query's leaf list for this probes_per_level (a property of the tree)."""
+        out = C.c_uint32(0)
+        _ffi.check(self._lib.cuddle_index_leaf_stride(self._handle, probes_per_level, C.byref(out)))
+        return int(out.value)
+
+    def route_device(self, d_queries, probes_per_level: int, flags: int = 0, stream: Optional[int] = None):
+        """Routing only, on the device: (leaves int32 [nq, leaf_stride], leaf_count int32 [nq])."""
+        import torch
+
+        assert d_queries.is_cuda and d_queries.dtype == torch.float32 and d_queries.is_contiguous()
+        nq, dim = d_queries.shape
+        if stream is None:
+            stream = torch.cuda.current_stream(d_queries.device).cuda_stream
+        stride = self.leaf_stride(probes_per_level)
+        leaves = torch.zeros((nq, stride), dtype=torch.int32, device=d_queries.device)
+        count = torch.zeros((nq,), dtype=torch.int32, device=d_queries.device)
+        if nq:
+            _ffi.check(self._lib.cuddle_route_batch_device(self._handle, C.c_void_p(d_queries.data_ptr()), nq, dim,
+                                                           probes_per_level, flags, C.c_void_p(leaves.data_ptr()), stride,
+                                                           C.c_void_p(count.data_ptr()), C.c_void_p(stream)))
+        return leaves, count
 
     def shard_ties(self, global_hist, stream: Optional[int] = None):
         """Step 2: `global_hist` = the histograms summed over all shards. Returns this shard's tie

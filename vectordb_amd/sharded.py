@@ -50,6 +50,33 @@ def merge_gathered(all_ids: torch.Tensor, all_dist: torch.Tensor, k: int):
     return si, sd, count
 
 
+def _via_host(group) -> bool:
+    """gloo moves CUDA tensors through the host on streams of its own; doing the staging here instead
+    (plain copies on the current stream) keeps a rehearsal of the N > 1 flow on a shared GPU deterministic.
+    RCCL ("nccl") works on the device buffers directly."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_reduce_sum(t: torch.Tensor, group) -> None:
+    if t.is_cuda and _via_host(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def _all_gather(out: torch.Tensor, mine: torch.Tensor, group) -> None:
+    """out[r] = rank r's `mine` (out: [world, *mine.shape])."""
+    mine = mine.contiguous()
+    if mine.is_cuda and _via_host(group):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather(list(h.unbind(0)), mine.cpu(), group=group)
+        out.copy_(h)
+    else:
+        dist.all_gather(list(out.unbind(0)), mine, group=group)
+
+
 class ShardedSearcher:
     """search_batch over `world` leaf shards. `local_search(queries, k, probes, rerank_factor)` must
     return (ids int64 [nq,k], dist f32 [nq,k], count) tensors on the collective's device; on the
@@ -72,8 +99,8 @@ class ShardedSearcher:
         nq = ids.shape[0]
         all_ids = torch.empty((self.world, nq, k), dtype=ids.dtype, device=ids.device)
         all_dist = torch.empty((self.world, nq, k), dtype=dist_.dtype, device=dist_.device)
-        dist.all_gather(list(all_ids.unbind(0)), ids.contiguous(), group=self.group)
-        dist.all_gather(list(all_dist.unbind(0)), dist_.contiguous(), group=self.group)
+        _all_gather(all_ids, ids, self.group)
+        _all_gather(all_dist, dist_, self.group)
         return merge_gathered(all_ids, all_dist, k)
 
 
@@ -103,19 +130,43 @@ class ExactShardedSearcher:
     shard_finish(queries, global_ties) -> (ids, dist, order, count) as tensors on the collective's
     device (`DeviceIndex` on the GPU)."""
 
-    def __init__(self, engine, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, engine, group: Optional[dist.ProcessGroup] = None, shard_routing: bool = True):
         self.engine = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # the tree is replicated, so routing gives the same leaf lists on every rank: each rank routes
+        # 1/world of the batch and the lists are all-gathered, instead of every rank routing all of it
+        self.shard_routing = shard_routing and self.world > 1 and hasattr(engine, "route_device")
+
+    def _route_sharded(self, queries: torch.Tensor, probes_per_level: int):
+        nq = queries.shape[0]
+        per = (nq + self.world - 1) // self.world
+        q0 = min(nq, self.rank * per)
+        q1 = min(nq, q0 + per)
+        leaves, count = self.engine.route_device(queries[q0:q1].contiguous(), probes_per_level)
+        stride = leaves.shape[1]
+        mine_l = torch.zeros((per, stride), dtype=leaves.dtype, device=leaves.device)
+        mine_c = torch.zeros((per,), dtype=count.dtype, device=count.device)
+        mine_l[:q1 - q0] = leaves
+        mine_c[:q1 - q0] = count
+        all_l = torch.empty((self.world, per, stride), dtype=leaves.dtype, device=leaves.device)
+        all_c = torch.empty((self.world, per), dtype=count.dtype, device=count.device)
+        _all_gather(all_l, mine_l, self.group)
+        _all_gather(all_c, mine_c, self.group)
+        return all_l.reshape(self.world * per, stride)[:nq].contiguous(), all_c.reshape(-1)[:nq].contiguous()
 
     def search_batch(self, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int):
-        hist = self.engine.shard_scan(queries, k, probes_per_level, rerank_factor)
+        if self.shard_routing:
+            leaves, count = self._route_sharded(queries, probes_per_level)
+            hist = self.engine.shard_scan(queries, k, probes_per_level, rerank_factor, leaves=leaves, leaf_count=count)
+        else:
+            hist = self.engine.shard_scan(queries, k, probes_per_level, rerank_factor)
         if self.world > 1:
-            dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=self.group)
+            _all_reduce_sum(hist, self.group)
         ties = self.engine.shard_ties(hist)
         if self.world > 1:
-            dist.all_reduce(ties, op=dist.ReduceOp.SUM, group=self.group)
+            _all_reduce_sum(ties, self.group)
         ids, dist_, order, count = self.engine.shard_finish(queries, ties)
         if self.world == 1:
             return ids, dist_, count
@@ -123,16 +174,27 @@ class ExactShardedSearcher:
         all_ids = torch.empty((self.world, nq, k), dtype=ids.dtype, device=ids.device)
         all_dist = torch.empty((self.world, nq, k), dtype=dist_.dtype, device=dist_.device)
         all_order = torch.empty((self.world, nq, k), dtype=order.dtype, device=order.device)
-        dist.all_gather(list(all_ids.unbind(0)), ids.contiguous(), group=self.group)
-        dist.all_gather(list(all_dist.unbind(0)), dist_.contiguous(), group=self.group)
-        dist.all_gather(list(all_order.unbind(0)), order.contiguous(), group=self.group)
+        _all_gather(all_ids, ids, self.group)
+        _all_gather(all_dist, dist_, self.group)
+        _all_gather(all_order, order, self.group)
         return merge_gathered_ordered(all_ids, all_dist, all_order, k)
 
 
-def exact_search_in_process(engines, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int):
+def exact_search_in_process(engines, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int,
+                            shard_routing: bool = False):
     """The ExactShardedSearcher protocol over several shards held by ONE process (sums instead of
-    all-reduces): for tests and for single-GPU rehearsals of an N-way split."""
-    hists = [e.shard_scan(queries, k, probes_per_level, rerank_factor) for e in engines]
+    all-reduces, concatenation instead of the all-gather of the routed slices): for tests and for
+    single-GPU rehearsals of an N-way split."""
+    if shard_routing:
+        nq, world = queries.shape[0], len(engines)
+        per = (nq + world - 1) // world
+        parts = [e.route_device(queries[min(nq, r * per):min(nq, (r + 1) * per)].contiguous(), probes_per_level)
+                 for r, e in enumerate(engines)]
+        leaves = torch.cat([p[0] for p in parts]).contiguous()
+        count = torch.cat([p[1] for p in parts]).contiguous()
+        hists = [e.shard_scan(queries, k, probes_per_level, rerank_factor, leaves=leaves, leaf_count=count) for e in engines]
+    else:
+        hists = [e.shard_scan(queries, k, probes_per_level, rerank_factor) for e in engines]
     ghist = torch.stack(hists).sum(dim=0).to(torch.int32).contiguous()
     ties = [e.shard_ties(ghist) for e in engines]
     gties = torch.stack(ties).sum(dim=0).to(torch.int32).contiguous()
