@@ -338,6 +338,14 @@ cuddle_status cuddle_merge_topk_ordered(const uint64_t *lists_ids, const float *
                                         uint32_t n_queries, uint32_t k, uint64_t *out_ids,
                                         float *out_dist, uint32_t *out_count);
 
+/* The same merge on device buffers, enqueued on `stream` (what the ranks run on the all-gathered
+ * lists): k <= 64 and n_lists * k <= 1024, else CUDDLE_ERR_UNSUPPORTED. */
+cuddle_status cuddle_merge_topk_ordered_device(const uint64_t *d_lists_ids, const float *d_lists_dist,
+                                               const uint64_t *d_lists_order, uint32_t n_lists,
+                                               uint32_t n_queries, uint32_t k, uint64_t *d_out_ids,
+                                               float *d_out_dist, uint32_t *d_out_count,
+                                               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,3 +88,45 @@ def test_route_device_matches_host_entry_point(gpu):
     st = dev._lib.cuddle_route_batch_device(dev._handle, C.c_void_p(dq.data_ptr()), 70, 48, 9, 0, C.c_void_p(small.data_ptr()), 1,
                                             C.c_void_p(cnt.data_ptr()), None)
     assert st == _ffi.ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("world,k,nq", [(2, 10, 33), (8, 10, 100), (3, 1, 5), (16, 64, 9), (5, 7, 257), (8, 100, 4)])
+def test_device_merge_matches_host_merge(gpu, world, k, nq):
+    """cuddle_merge_topk_ordered_device against the host merge on lists with padding, equal distances
+    (the order key decides) and signed zeros; shapes beyond the kernel's limits are refused."""
+    import ctypes as C
+    from vectordb_amd import _ffi
+
+    rng = np.random.default_rng(world * 1000 + k)
+    ids = rng.integers(0, 1 << 40, (world, nq, k)).astype(np.uint64)
+    dist = np.round(rng.random((world, nq, k)) * 4).astype(np.float32) / 4  # many equal distances
+    dist[rng.random(dist.shape) < 0.05] = -0.0
+    dist.sort(axis=2)
+    order = rng.permutation(world * nq * k).reshape(world, nq, k).astype(np.uint64)
+    fill = rng.integers(0, k + 1, (world, nq))  # entries per list; the rest is padding
+    pad = np.arange(k)[None, None, :] >= fill[:, :, None]
+    ids[pad], dist[pad], order[pad] = np.uint64(0xFFFFFFFFFFFFFFFF), np.inf, np.uint64(0xFFFFFFFFFFFFFFFF)
+    lib = _ffi.lib()
+    h_ids = np.zeros((nq, k), dtype=np.uint64)
+    h_dist = np.zeros((nq, k), dtype=np.float32)
+    h_cnt = np.zeros(nq, dtype=np.uint32)
+    _ffi.check(lib.cuddle_merge_topk_ordered(_ffi.ptr(ids), _ffi.ptr(dist), _ffi.ptr(order), world, nq, k,
+                                             _ffi.ptr(h_ids), _ffi.ptr(h_dist), _ffi.ptr(h_cnt)))
+    dev = torch.device("cuda", gpu)
+    t_ids = torch.from_numpy(ids.view(np.int64)).to(dev)
+    t_dist = torch.from_numpy(dist).to(dev)
+    t_order = torch.from_numpy(order.view(np.int64)).to(dev)
+    o_ids = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+    o_dist = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+    o_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+    st = lib.cuddle_merge_topk_ordered_device(t_ids.data_ptr(), t_dist.data_ptr(), t_order.data_ptr(), world, nq, k,
+                                              o_ids.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr(), None)
+    if k > 64 or world * k > 1024:
+        assert st == _ffi.ERR_UNSUPPORTED
+        return
+    _ffi.check(st)
+    torch.cuda.synchronize()
+    assert np.array_equal(o_cnt.cpu().numpy().astype(np.uint32), h_cnt)
+    assert np.array_equal(o_ids.cpu().numpy().view(np.uint64), h_ids)
+    # distances equal as floats (a signed zero may come from either of two tied lists only if their order keys tie, which they cannot)
+    assert np.array_equal(_bits(o_dist.cpu().numpy()), _bits(h_dist))

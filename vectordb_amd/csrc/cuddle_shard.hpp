@@ -144,4 +144,72 @@ shard_select_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const
     if (tid == 0) sel_count[q] = min(sel_off[nl], sel_stride);
 }
 
+// Merge of the shards' result lists (cuddle_shard_finish: ascending, padded with id = ~0) into the
+// global top-k per query, ascending by (distance, order): the finalize_results order of the unsharded
+// index (hierarchical.rs:678-691). lists laid out [n_lists][nq][k], n_lists * k <= 64 * KPL, k <= 64.
+// One wave per query, entries in registers, k rounds of "smallest (distance, order) of the wave".
+template <int KPL>
+__global__ void __launch_bounds__(256)
+merge_ordered_kernel(const uint64_t *ids, const float *dist, const uint64_t *order, uint32_t n_lists, uint32_t nq,
+                     uint32_t k, uint64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const uint32_t total = n_lists * k;
+    uint32_t dk[KPL];
+    uint64_t od[KPL];
+#pragma unroll
+    for (int t = 0; t < KPL; ++t) {
+        const uint32_t e = t * 64 + lane;
+        dk[t] = 0xFFFFFFFFu;
+        od[t] = ~0ull;
+        if (e < total) {
+            const uint64_t o = ((uint64_t)(e / k) * nq + q) * k + e % k;
+            if (ids[o] != ~0ull) {
+                dk[t] = f32_key(dist[o] + 0.0f); // -0 orders as +0, as the float comparison does
+                od[t] = order[o];
+            }
+        }
+    }
+    uint32_t mine = 0xFFFFFFFFu, n = 0; // lane r keeps the entry index of the r-th winner
+    for (uint32_t r = 0; r < k; ++r) {
+        uint32_t bd = dk[0], bt = 0;
+        uint64_t bo = od[0];
+#pragma unroll
+        for (int t = 1; t < KPL; ++t)
+            if (dk[t] < bd || (dk[t] == bd && od[t] < bo)) {
+                bd = dk[t];
+                bo = od[t];
+                bt = t;
+            }
+        const uint32_t md = wave_min_u32(bd);
+        const uint64_t mo = wave_min_u64(bd == md ? bo : ~0ull);
+        if (md == 0xFFFFFFFFu && mo == ~0ull) break; // only padding left
+        const bool win = bd == md && bo == mo;       // order keys are unique: one lane
+        const uint64_t wb = __ballot(win);
+        const uint32_t src = (uint32_t)__ffsll((unsigned long long)wb) - 1;
+        const uint32_t e_w = (uint32_t)__builtin_amdgcn_readlane((int)(bt * 64 + lane), src);
+        if (lane == r) mine = e_w;
+        if (win && lane == src) {
+#pragma unroll
+            for (int t = 0; t < KPL; ++t)
+                if ((uint32_t)t == bt) {
+                    dk[t] = 0xFFFFFFFFu;
+                    od[t] = ~0ull;
+                }
+        }
+        ++n;
+    }
+    for (uint32_t i = lane; i < k; i += 64) {
+        if (i < n) {
+            const uint64_t o = ((uint64_t)(mine / k) * nq + q) * k + mine % k;
+            out_ids[(uint64_t)q * k + i] = ids[o];
+            out_dist[(uint64_t)q * k + i] = dist[o];
+        } else {
+            out_ids[(uint64_t)q * k + i] = ~0ull;
+            out_dist[(uint64_t)q * k + i] = __builtin_inff();
+        }
+    }
+    if (lane == 0 && out_count) out_count[q] = n;
+}
+
 } // namespace cuddle

@@ -108,6 +108,16 @@ def merge_gathered_ordered(all_ids: torch.Tensor, all_dist: torch.Tensor, all_or
     """all_*: [world, nq, k]. Ascending by (distance, order), the rule of cuddle_merge_topk_ordered.
     Returns (ids [nq,k], dist [nq,k], count [nq])."""
     world, nq, kk = all_dist.shape
+    if all_dist.is_cuda and kk == k and k <= 64 and world * k <= 1024:  # one kernel (cuddle_merge_topk_ordered_device)
+        from . import _ffi
+        ids = torch.empty((nq, k), dtype=torch.int64, device=all_dist.device)
+        dd = torch.empty((nq, k), dtype=torch.float32, device=all_dist.device)
+        cnt = torch.empty((nq,), dtype=torch.int32, device=all_dist.device)
+        ai, ad, ao = all_ids.contiguous(), all_dist.contiguous(), all_order.contiguous()
+        _ffi.check(_ffi.lib().cuddle_merge_topk_ordered_device(
+            ai.data_ptr(), ad.data_ptr(), ao.data_ptr(), world, nq, k, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
+            torch.cuda.current_stream(all_dist.device).cuda_stream))
+        return ids, dd, cnt
     d = all_dist.permute(1, 0, 2).reshape(nq, world * kk)
     i = all_ids.permute(1, 0, 2).reshape(nq, world * kk)
     o = all_order.permute(1, 0, 2).reshape(nq, world * kk)
@@ -146,15 +156,13 @@ class ExactShardedSearcher:
         q1 = min(nq, q0 + per)
         leaves, count = self.engine.route_device(queries[q0:q1].contiguous(), probes_per_level)
         stride = leaves.shape[1]
-        mine_l = torch.zeros((per, stride), dtype=leaves.dtype, device=leaves.device)
-        mine_c = torch.zeros((per,), dtype=count.dtype, device=count.device)
-        mine_l[:q1 - q0] = leaves
-        mine_c[:q1 - q0] = count
-        all_l = torch.empty((self.world, per, stride), dtype=leaves.dtype, device=leaves.device)
-        all_c = torch.empty((self.world, per), dtype=count.dtype, device=count.device)
-        _all_gather(all_l, mine_l, self.group)
-        _all_gather(all_c, mine_c, self.group)
-        return all_l.reshape(self.world * per, stride)[:nq].contiguous(), all_c.reshape(-1)[:nq].contiguous()
+        mine = torch.zeros((per, stride + 1), dtype=leaves.dtype, device=leaves.device)  # lists and counts in one message
+        mine[:q1 - q0, :stride] = leaves
+        mine[:q1 - q0, stride] = count
+        everyone = torch.empty((self.world, per, stride + 1), dtype=leaves.dtype, device=leaves.device)
+        _all_gather(everyone, mine, self.group)
+        everyone = everyone.reshape(self.world * per, stride + 1)[:nq]
+        return everyone[:, :stride].contiguous(), everyone[:, stride].contiguous()
 
     def search_batch(self, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int):
         if self.shard_routing:
@@ -171,13 +179,12 @@ class ExactShardedSearcher:
         if self.world == 1:
             return ids, dist_, count
         nq = ids.shape[0]
-        all_ids = torch.empty((self.world, nq, k), dtype=ids.dtype, device=ids.device)
-        all_dist = torch.empty((self.world, nq, k), dtype=dist_.dtype, device=dist_.device)
-        all_order = torch.empty((self.world, nq, k), dtype=order.dtype, device=order.device)
-        _all_gather(all_ids, ids, self.group)
-        _all_gather(all_dist, dist_, self.group)
-        _all_gather(all_order, order, self.group)
-        return merge_gathered_ordered(all_ids, all_dist, all_order, k)
+        # one message per rank: [3][nq][k] int64 = ids, order keys, distance bits
+        mine = torch.stack((ids, order, dist_.contiguous().view(torch.int32).to(torch.int64)))
+        everyone = torch.empty((self.world, 3, nq, k), dtype=torch.int64, device=ids.device)
+        _all_gather(everyone, mine, self.group)
+        all_dist = everyone[:, 2].to(torch.int32).view(torch.float32)
+        return merge_gathered_ordered(everyone[:, 0], all_dist, everyone[:, 1], k)
 
 
 def exact_search_in_process(engines, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int,
