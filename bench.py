@@ -242,8 +242,11 @@ def main():
         def shard_scan(self, q, kk, pp, rr, leaves=None, leaf_count=None):
             return dev_index.shard_scan(q, kk, pp, rr, flags, leaves=leaves, leaf_count=leaf_count)
 
-        def route_device(self, q, pp):
-            return dev_index.route_device(q, pp, flags)
+        def route_device(self, q, pp, out=None):
+            return dev_index.route_device(q, pp, flags, out=out)
+
+        leaf_stride = staticmethod(dev_index.leaf_stride)
+        packed_len = staticmethod(dev_index.packed_len)
 
         shard_ties = staticmethod(dev_index.shard_ties)
         shard_finish = staticmethod(dev_index.shard_finish)

@@ -339,10 +339,14 @@ cuddle_status cuddle_merge_topk_ordered(const uint64_t *lists_ids, const float *
                                         float *out_dist, uint32_t *out_count);
 
 /* The same merge on device buffers, enqueued on `stream` (what the ranks run on the all-gathered
- * lists): k <= 64 and n_lists * k <= 1024, else CUDDLE_ERR_UNSUPPORTED. */
+ * lists): k <= 64 and n_lists * k <= 1024, else CUDDLE_ERR_UNSUPPORTED. list_stride_bytes = 0:
+ * the arrays are laid out [n_lists][n_queries][k] like the host merge's. Otherwise list l of each
+ * of the three arrays ([n_queries][k]) starts list_stride_bytes (a multiple of 8) after list
+ * l - 1, so that a rank's ids, distances and order keys can travel as one message. */
 cuddle_status cuddle_merge_topk_ordered_device(const uint64_t *d_lists_ids, const float *d_lists_dist,
                                                const uint64_t *d_lists_order, uint32_t n_lists,
-                                               uint32_t n_queries, uint32_t k, uint64_t *d_out_ids,
+                                               uint32_t n_queries, uint32_t k,
+                                               uint64_t list_stride_bytes, uint64_t *d_out_ids,
                                                float *d_out_dist, uint32_t *d_out_count,
                                                void *stream);
 

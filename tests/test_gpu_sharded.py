@@ -24,12 +24,13 @@ def _check(fi, gpu, q, cases, worlds=(2, 3)):
         shards = [DeviceIndex(fi.shard(r, world), gpu) for r in range(world)]
         for (k, probes, rf) in cases:
             ids0, d0, c0 = full.search_batch_device(dq, k, probes, rf)
-            for shard_routing in (False, True):  # every shard routes the batch / each routes a slice of it
-                ids1, d1, c1 = exact_search_in_process(shards, dq, k, probes, rf, shard_routing=shard_routing)
+            # every shard routes the batch / each routes a slice of it / the same, written into message buffers
+            for shard_routing, packed in ((False, False), (True, False), (True, True), (False, True)):
+                ids1, d1, c1 = exact_search_in_process(shards, dq, k, probes, rf, shard_routing=shard_routing, packed=packed)
                 torch.cuda.synchronize()
-                assert torch.equal(c0.cpu(), c1.cpu()), (world, k, probes, rf, shard_routing)
-                assert torch.equal(ids0.cpu(), ids1.cpu()), (world, k, probes, rf, shard_routing)
-                assert np.array_equal(_bits(d0.cpu().numpy()), _bits(d1.cpu().numpy())), (world, k, probes, rf, shard_routing)
+                assert torch.equal(c0.cpu(), c1.cpu()), (world, k, probes, rf, shard_routing, packed)
+                assert torch.equal(ids0.cpu(), ids1.cpu()), (world, k, probes, rf, shard_routing, packed)
+                assert np.array_equal(_bits(d0.cpu().numpy()), _bits(d1.cpu().numpy())), (world, k, probes, rf, shard_routing, packed)
 
 
 @pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
@@ -119,7 +120,7 @@ def test_device_merge_matches_host_merge(gpu, world, k, nq):
     o_ids = torch.zeros((nq, k), dtype=torch.int64, device=dev)
     o_dist = torch.zeros((nq, k), dtype=torch.float32, device=dev)
     o_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
-    st = lib.cuddle_merge_topk_ordered_device(t_ids.data_ptr(), t_dist.data_ptr(), t_order.data_ptr(), world, nq, k,
+    st = lib.cuddle_merge_topk_ordered_device(t_ids.data_ptr(), t_dist.data_ptr(), t_order.data_ptr(), world, nq, k, 0,
                                               o_ids.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr(), None)
     if k > 64 or world * k > 1024:
         assert st == _ffi.ERR_UNSUPPORTED

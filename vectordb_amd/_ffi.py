@@ -129,7 +129,7 @@ SIGNATURES = {
     "cuddle_shard_ties": (_int, [_vp, _vp, _vp, _vp]),
     "cuddle_shard_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cuddle_merge_topk_ordered": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
-    "cuddle_merge_topk_ordered_device": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "cuddle_merge_topk_ordered_device": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u64, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -1643,18 +1643,22 @@ extern "C" cuddle_status cuddle_shard_finish(cuddle_index *idx, const float *d_q
 // ---------------------------------------------------------------------------------------------
 extern "C" cuddle_status cuddle_merge_topk_ordered_device(const uint64_t *d_lists_ids, const float *d_lists_dist,
                                                           const uint64_t *d_lists_order, uint32_t n_lists, uint32_t n_queries,
-                                                          uint32_t k, uint64_t *d_out_ids, float *d_out_dist,
-                                                          uint32_t *d_out_count, void *stream) {
+                                                          uint32_t k, uint64_t list_stride_bytes, uint64_t *d_out_ids,
+                                                          float *d_out_dist, uint32_t *d_out_count, void *stream) {
     if (!d_lists_ids || !d_lists_dist || !d_lists_order || !d_out_ids || !d_out_dist) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
     if (k == 0 || n_lists == 0) return fail(CUDDLE_ERR_BAD_ARG, "k and n_lists must be >= 1");
     if (k > 64 || (uint64_t)n_lists * k > 64 * 16) return fail(CUDDLE_ERR_UNSUPPORTED, "device merge handles k <= 64 and n_lists * k <= 1024");
+    if (list_stride_bytes % 8) return fail(CUDDLE_ERR_BAD_ARG, "list_stride_bytes must be a multiple of 8");
     if (n_queries == 0) return CUDDLE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t total = n_lists * k;
     const dim3 grid((n_queries + 3) / 4), block(256);
+    const uint64_t dense = (uint64_t)n_queries * k; // list_stride_bytes = 0: each array is [n_lists][n_queries][k]
+    const uint64_t si = list_stride_bytes ? list_stride_bytes : dense * 8, sd = list_stride_bytes ? list_stride_bytes : dense * 4,
+                   so = si;
 #define CUDDLE_MERGE(KPL)                                                                                              \
-    hipLaunchKernelGGL(merge_ordered_kernel<KPL>, grid, block, 0, s, d_lists_ids, d_lists_dist, d_lists_order, n_lists, \
-                       n_queries, k, d_out_ids, d_out_dist, d_out_count)
+    hipLaunchKernelGGL(merge_ordered_kernel<KPL>, grid, block, 0, s, d_lists_ids, d_lists_dist, d_lists_order, si, sd, \
+                       so, n_lists, n_queries, k, d_out_ids, d_out_dist, d_out_count)
     if (total <= 64) CUDDLE_MERGE(1);
     else if (total <= 128) CUDDLE_MERGE(2);
     else if (total <= 256) CUDDLE_MERGE(4);

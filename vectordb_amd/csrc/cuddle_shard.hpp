@@ -146,14 +146,20 @@ shard_select_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const
 
 // Merge of the shards' result lists (cuddle_shard_finish: ascending, padded with id = ~0) into the
 // global top-k per query, ascending by (distance, order): the finalize_results order of the unsharded
-// index (hierarchical.rs:678-691). lists laid out [n_lists][nq][k], n_lists * k <= 64 * KPL, k <= 64.
+// index (hierarchical.rs:678-691). List l of an array ([nq][k]) starts that array's stride (bytes) after
+// list l - 1; n_lists * k <= 64 * KPL, k <= 64.
 // One wave per query, entries in registers, k rounds of "smallest (distance, order) of the wave".
 template <int KPL>
 __global__ void __launch_bounds__(256)
-merge_ordered_kernel(const uint64_t *ids, const float *dist, const uint64_t *order, uint32_t n_lists, uint32_t nq,
-                     uint32_t k, uint64_t *out_ids, float *out_dist, uint32_t *out_count) {
+merge_ordered_kernel(const uint64_t *ids, const float *dist, const uint64_t *order, uint64_t ids_stride,
+                     uint64_t dist_stride, uint64_t order_stride, uint32_t n_lists,
+                     uint32_t nq, uint32_t k, uint64_t *out_ids, float *out_dist, uint32_t *out_count) {
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq) return;
+    auto at = [&](const auto *base, uint64_t list_stride, uint32_t e) { // entry e = (list, rank in list) of this query
+        typedef decltype(base) P;
+        return reinterpret_cast<P>(reinterpret_cast<const char *>(base) + (uint64_t)(e / k) * list_stride) + (uint64_t)q * k + e % k;
+    };
     const uint32_t total = n_lists * k;
     uint32_t dk[KPL];
     uint64_t od[KPL];
@@ -163,10 +169,9 @@ merge_ordered_kernel(const uint64_t *ids, const float *dist, const uint64_t *ord
         dk[t] = 0xFFFFFFFFu;
         od[t] = ~0ull;
         if (e < total) {
-            const uint64_t o = ((uint64_t)(e / k) * nq + q) * k + e % k;
-            if (ids[o] != ~0ull) {
-                dk[t] = f32_key(dist[o] + 0.0f); // -0 orders as +0, as the float comparison does
-                od[t] = order[o];
+            if (*at(ids, ids_stride, e) != ~0ull) {
+                dk[t] = f32_key(*at(dist, dist_stride, e) + 0.0f); // -0 orders as +0, as the float comparison does
+                od[t] = *at(order, order_stride, e);
             }
         }
     }
@@ -201,9 +206,8 @@ merge_ordered_kernel(const uint64_t *ids, const float *dist, const uint64_t *ord
     }
     for (uint32_t i = lane; i < k; i += 64) {
         if (i < n) {
-            const uint64_t o = ((uint64_t)(mine / k) * nq + q) * k + mine % k;
-            out_ids[(uint64_t)q * k + i] = ids[o];
-            out_dist[(uint64_t)q * k + i] = dist[o];
+            out_ids[(uint64_t)q * k + i] = *at(ids, ids_stride, mine);
+            out_dist[(uint64_t)q * k + i] = *at(dist, dist_stride, mine);
         } else {
             out_ids[(uint64_t)q * k + i] = ~0ull;
             out_dist[(uint64_t)q * k + i] = __builtin_inff();

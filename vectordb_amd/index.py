@@ -131,11 +131,11 @@ class DeviceIndex:
                                                    rerank_factor, flags, C.c_void_p(hist.data_ptr()), C.byref(stride),
                                                    C.c_void_p(stream)))
         else:  # routing done elsewhere (route_device on slices of the batch, all-gathered)
-            assert leaves.is_cuda and leaves.dtype == torch.int32 and leaves.is_contiguous() and leaves.shape[0] == nq
+            assert leaves.is_cuda and leaves.dtype == torch.int32 and leaves.stride(1) == 1 and leaves.shape[0] == nq
             assert leaf_count.is_cuda and leaf_count.dtype == torch.int32 and leaf_count.is_contiguous()
             _ffi.check(self._lib.cuddle_shard_scan_leaves(self._handle, C.c_void_p(d_queries.data_ptr()), nq, dim, k,
                                                           probes_per_level, rerank_factor, flags,
-                                                          C.c_void_p(leaves.data_ptr()), leaves.shape[1],
+                                                          C.c_void_p(leaves.data_ptr()), leaves.stride(0),
                                                           C.c_void_p(leaf_count.data_ptr()), C.c_void_p(hist.data_ptr()),
                                                           C.byref(stride), C.c_void_p(stream)))
         self._shard = (nq, k, int(stride.value))
@@ -147,8 +147,10 @@ class DeviceIndex:
         _ffi.check(self._lib.cuddle_index_leaf_stride(self._handle, probes_per_level, C.byref(out)))
         return int(out.value)
 
-    def route_device(self, d_queries, probes_per_level: int, flags: int = 0, stream: Optional[int] = None):
-        """Routing only, on the device: (leaves int32 [nq, leaf_stride], leaf_count int32 [nq])."""
+    def route_device(self, d_queries, probes_per_level: int, flags: int = 0, stream: Optional[int] = None, out=None):
+        """Routing only, on the device: (leaves int32 [nq, leaf_stride], leaf_count int32 [nq]).
+        out: an int32 CUDA tensor [>= nq, >= leaf_stride] (unit stride along a row) that receives the
+        lists in its first leaf_stride columns; `leaves` is then a view of it."""
         import torch
 
         assert d_queries.is_cuda and d_queries.dtype == torch.float32 and d_queries.is_contiguous()
@@ -156,12 +158,16 @@ class DeviceIndex:
         if stream is None:
             stream = torch.cuda.current_stream(d_queries.device).cuda_stream
         stride = self.leaf_stride(probes_per_level)
-        leaves = torch.zeros((nq, stride), dtype=torch.int32, device=d_queries.device)
+        if out is None:
+            leaves = torch.zeros((nq, stride), dtype=torch.int32, device=d_queries.device)
+        else:
+            assert out.is_cuda and out.dtype == torch.int32 and out.stride(1) == 1 and out.shape[0] >= nq and out.shape[1] >= stride
+            leaves = out[:nq, :stride]
         count = torch.zeros((nq,), dtype=torch.int32, device=d_queries.device)
         if nq:
             _ffi.check(self._lib.cuddle_route_batch_device(self._handle, C.c_void_p(d_queries.data_ptr()), nq, dim,
-                                                           probes_per_level, flags, C.c_void_p(leaves.data_ptr()), stride,
-                                                           C.c_void_p(count.data_ptr()), C.c_void_p(stream)))
+                                                           probes_per_level, flags, C.c_void_p(leaves.data_ptr()),
+                                                           leaves.stride(0), C.c_void_p(count.data_ptr()), C.c_void_p(stream)))
         return leaves, count
 
     def shard_ties(self, global_hist, stream: Optional[int] = None):
@@ -178,9 +184,16 @@ class DeviceIndex:
                                                C.c_void_p(stream)))
         return ties
 
-    def shard_finish(self, d_queries, global_ties, stream: Optional[int] = None):
+    @staticmethod
+    def packed_len(nq: int, k: int) -> int:
+        """int64 words of one shard's packed result: ids [nq*k], order keys [nq*k], distances (f32, two per word)."""
+        return 2 * nq * k + (nq * k + 1) // 2
+
+    def shard_finish(self, d_queries, global_ties, stream: Optional[int] = None, packed=None):
         """Step 3: returns (ids int64 view of u64, dist f32, order int64 view of u64, count int32),
-        each [nq, k] / [nq]: this shard's top-k of the global selection."""
+        each [nq, k] / [nq]: this shard's top-k of the global selection. packed: an int64 CUDA tensor
+        of packed_len(nq, k) words that receives ids, order keys and distances back to back (one
+        message for the all-gather); the returned tensors are then views of it."""
         import torch
 
         nq, k, _ = self._shard
@@ -188,9 +201,15 @@ class DeviceIndex:
         if stream is None:
             stream = torch.cuda.current_stream(dev).cuda_stream
         assert global_ties.is_contiguous() and global_ties.dtype == torch.int32
-        ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
-        dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
-        order = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        if packed is None:
+            ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            order = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        else:
+            assert packed.is_cuda and packed.dtype == torch.int64 and packed.is_contiguous() and packed.numel() >= self.packed_len(nq, k)
+            n = nq * k
+            ids, order = packed[:n].view(nq, k), packed[n:2 * n].view(nq, k)
+            dist = packed[2 * n:].view(torch.float32)[:n].view(nq, k)
         count = torch.empty((nq,), dtype=torch.int32, device=dev)
         _ffi.check(self._lib.cuddle_shard_finish(self._handle, C.c_void_p(d_queries.data_ptr()),
                                                  C.c_void_p(global_ties.data_ptr()), C.c_void_p(ids.data_ptr()),

@@ -115,7 +115,7 @@ def merge_gathered_ordered(all_ids: torch.Tensor, all_dist: torch.Tensor, all_or
         cnt = torch.empty((nq,), dtype=torch.int32, device=all_dist.device)
         ai, ad, ao = all_ids.contiguous(), all_dist.contiguous(), all_order.contiguous()
         _ffi.check(_ffi.lib().cuddle_merge_topk_ordered_device(
-            ai.data_ptr(), ad.data_ptr(), ao.data_ptr(), world, nq, k, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
+            ai.data_ptr(), ad.data_ptr(), ao.data_ptr(), world, nq, k, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
             torch.cuda.current_stream(all_dist.device).cuda_stream))
         return ids, dd, cnt
     d = all_dist.permute(1, 0, 2).reshape(nq, world * kk)
@@ -134,6 +134,27 @@ def merge_gathered_ordered(all_ids: torch.Tensor, all_dist: torch.Tensor, all_or
     return si, sd, count
 
 
+def merge_gathered_packed(everyone: torch.Tensor, nq: int, k: int):
+    """everyone: [world, words] int64, each row one shard's packed result (DeviceIndex.packed_len:
+    ids, order keys, f32 distances back to back). Same result as merge_gathered_ordered."""
+    world, words = everyone.shape
+    n = nq * k
+    if everyone.is_cuda and k <= 64 and world * k <= 1024:  # the merge kernel reads the messages in place
+        from . import _ffi
+        ids = torch.empty((nq, k), dtype=torch.int64, device=everyone.device)
+        dd = torch.empty((nq, k), dtype=torch.float32, device=everyone.device)
+        cnt = torch.empty((nq,), dtype=torch.int32, device=everyone.device)
+        base = everyone.data_ptr()
+        _ffi.check(_ffi.lib().cuddle_merge_topk_ordered_device(
+            base, base + 2 * n * 8, base + n * 8, world, nq, k, words * 8, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
+            torch.cuda.current_stream(everyone.device).cuda_stream))
+        return ids, dd, cnt
+    all_ids = everyone[:, :n].reshape(world, nq, k)
+    all_order = everyone[:, n:2 * n].reshape(world, nq, k)
+    all_dist = everyone[:, 2 * n:].contiguous().view(torch.float32)[:, :n].reshape(world, nq, k)
+    return merge_gathered_ordered(all_ids, all_dist, all_order, k)
+
+
 class ExactShardedSearcher:
     """Bit-exact leaf-sharded search. `engine` is this rank's shard and provides
     shard_scan(queries, k, probes, rf) -> hist, shard_ties(global_hist) -> ties,
@@ -148,20 +169,30 @@ class ExactShardedSearcher:
         # the tree is replicated, so routing gives the same leaf lists on every rank: each rank routes
         # 1/world of the batch and the lists are all-gathered, instead of every rank routing all of it
         self.shard_routing = shard_routing and self.world > 1 and hasattr(engine, "route_device")
+        # engines that can write their outputs into caller-given message buffers (DeviceIndex) save the packing copies
+        self.packed = hasattr(engine, "packed_len")
 
     def _route_sharded(self, queries: torch.Tensor, probes_per_level: int):
         nq = queries.shape[0]
         per = (nq + self.world - 1) // self.world
         q0 = min(nq, self.rank * per)
         q1 = min(nq, q0 + per)
-        leaves, count = self.engine.route_device(queries[q0:q1].contiguous(), probes_per_level)
-        stride = leaves.shape[1]
-        mine = torch.zeros((per, stride + 1), dtype=leaves.dtype, device=leaves.device)  # lists and counts in one message
-        mine[:q1 - q0, :stride] = leaves
-        mine[:q1 - q0, stride] = count
-        everyone = torch.empty((self.world, per, stride + 1), dtype=leaves.dtype, device=leaves.device)
+        if self.packed:  # the engine writes the lists straight into the message: [per][stride + 1], last column = counts
+            stride = self.engine.leaf_stride(probes_per_level)
+            mine = torch.empty((per, stride + 1), dtype=torch.int32, device=queries.device)
+            _, count = self.engine.route_device(queries[q0:q1], probes_per_level, out=mine)
+            mine[:q1 - q0, stride] = count
+        else:
+            leaves, count = self.engine.route_device(queries[q0:q1].contiguous(), probes_per_level)
+            stride = leaves.shape[1]
+            mine = torch.zeros((per, stride + 1), dtype=leaves.dtype, device=leaves.device)
+            mine[:q1 - q0, :stride] = leaves
+            mine[:q1 - q0, stride] = count
+        everyone = torch.empty((self.world, per, stride + 1), dtype=mine.dtype, device=mine.device)
         _all_gather(everyone, mine, self.group)
-        everyone = everyone.reshape(self.world * per, stride + 1)[:nq]
+        everyone = everyone.reshape(self.world * per, stride + 1)[:nq]  # rows past a rank's slice lie past nq
+        if self.packed:
+            return everyone[:, :stride], everyone[:, stride].contiguous()  # the lists stay where the gather put them
         return everyone[:, :stride].contiguous(), everyone[:, stride].contiguous()
 
     def search_batch(self, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int):
@@ -175,6 +206,14 @@ class ExactShardedSearcher:
         ties = self.engine.shard_ties(hist)
         if self.world > 1:
             _all_reduce_sum(ties, self.group)
+        if self.packed and self.world > 1:
+            nq = queries.shape[0]
+            words = self.engine.packed_len(nq, k)
+            mine = torch.empty((words,), dtype=torch.int64, device=queries.device)
+            self.engine.shard_finish(queries, ties, packed=mine)
+            everyone = torch.empty((self.world, words), dtype=torch.int64, device=queries.device)
+            _all_gather(everyone, mine, self.group)
+            return merge_gathered_packed(everyone, nq, k)
         ids, dist_, order, count = self.engine.shard_finish(queries, ties)
         if self.world == 1:
             return ids, dist_, count
@@ -188,23 +227,39 @@ class ExactShardedSearcher:
 
 
 def exact_search_in_process(engines, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int,
-                            shard_routing: bool = False):
+                            shard_routing: bool = False, packed: bool = False):
     """The ExactShardedSearcher protocol over several shards held by ONE process (sums instead of
-    all-reduces, concatenation instead of the all-gather of the routed slices): for tests and for
-    single-GPU rehearsals of an N-way split."""
+    all-reduces, concatenation instead of the all-gathers): for tests and for single-GPU rehearsals
+    of an N-way split. packed: the engines write into message buffers as they do between ranks."""
+    nq, world = queries.shape[0], len(engines)
     if shard_routing:
-        nq, world = queries.shape[0], len(engines)
         per = (nq + world - 1) // world
-        parts = [e.route_device(queries[min(nq, r * per):min(nq, (r + 1) * per)].contiguous(), probes_per_level)
-                 for r, e in enumerate(engines)]
-        leaves = torch.cat([p[0] for p in parts]).contiguous()
-        count = torch.cat([p[1] for p in parts]).contiguous()
+        if packed:
+            stride = engines[0].leaf_stride(probes_per_level)
+            everyone = torch.empty((world, per, stride + 1), dtype=torch.int32, device=queries.device)
+            for r, e in enumerate(engines):
+                q0, q1 = min(nq, r * per), min(nq, (r + 1) * per)
+                _, c = e.route_device(queries[q0:q1], probes_per_level, out=everyone[r])
+                everyone[r, :q1 - q0, stride] = c
+            everyone = everyone.reshape(world * per, stride + 1)[:nq]
+            leaves, count = everyone[:, :stride], everyone[:, stride].contiguous()
+        else:
+            parts = [e.route_device(queries[min(nq, r * per):min(nq, (r + 1) * per)].contiguous(), probes_per_level)
+                     for r, e in enumerate(engines)]
+            leaves = torch.cat([p[0] for p in parts]).contiguous()
+            count = torch.cat([p[1] for p in parts]).contiguous()
         hists = [e.shard_scan(queries, k, probes_per_level, rerank_factor, leaves=leaves, leaf_count=count) for e in engines]
     else:
         hists = [e.shard_scan(queries, k, probes_per_level, rerank_factor) for e in engines]
     ghist = torch.stack(hists).sum(dim=0).to(torch.int32).contiguous()
     ties = [e.shard_ties(ghist) for e in engines]
     gties = torch.stack(ties).sum(dim=0).to(torch.int32).contiguous()
+    if packed:
+        words = engines[0].packed_len(nq, k)
+        everyone = torch.empty((world, words), dtype=torch.int64, device=queries.device)
+        for r, e in enumerate(engines):
+            e.shard_finish(queries, gties, packed=everyone[r])
+        return merge_gathered_packed(everyone, nq, k)
     outs = [e.shard_finish(queries, gties) for e in engines]
     all_ids = torch.stack([o[0] for o in outs])
     all_dist = torch.stack([o[1] for o in outs])
