@@ -456,7 +456,7 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
             }
             ST_TRY(dev_alloc(ix, nodes.size() * (size_t)split_kp(D) * 2, &g.table));
             ST_TRY(dev_alloc(ix, nodes.size(), &g.sqn));
-            hipLaunchKernelGGL(level_table_kernel, dim3(((uint32_t)nodes.size() + 127) / 128), dim3(128), 0, 0, centroids,
+            hipLaunchKernelGGL(level_table_kernel, dim3(((uint32_t)nodes.size() + 3) / 4), dim3(256), 0, 0, centroids,
                                g.nodes, (uint32_t)nodes.size(), D, split_kp(D), g.mu, g.table, g.sqn);
             std::vector<float> h(nodes.size());
             HIP_TRY(hipMemcpy(h.data(), g.sqn, nodes.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -1302,7 +1302,7 @@ extern "C" cuddle_status cuddle_kmeans_assign(const float *d_vectors, uint64_t n
         hipLaunchKernelGGL(level_sum_kernel, dim3((dim + 63) / 64, 256), dim3(64), 0, stream, d_centroids, (const uint32_t *)nullptr, k, dim, acc);
         hipLaunchKernelGGL(level_mean_kernel, dim3((dim + 255) / 256), dim3(256), 0, stream, acc, k, dim, mu);
     }
-    hipLaunchKernelGGL(level_table_kernel, dim3((k + 127) / 128), dim3(128), 0, stream, d_centroids, (const uint32_t *)nullptr, k, dim, kp, mu,
+    hipLaunchKernelGGL(level_table_kernel, dim3((k + 3) / 4), dim3(256), 0, stream, d_centroids, (const uint32_t *)nullptr, k, dim, kp, mu,
                        table, csq);
     std::vector<float> h(k);
     HIP_TRY(hipMemcpyAsync(h.data(), csq, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, stream));

@@ -713,22 +713,24 @@ __device__ __forceinline__ void bf16_split_store(uint16_t *row, uint32_t i, floa
 // the j-th node of the level (breadth-first order = the frontier order every query sees when all
 // earlier levels keep all their nodes) minus mu (L2: the level's mean centroid, which keeps the norms
 // and so the rounding error of the norm expansion small; other metrics: mu = 0), plus the squared
-// norm of the f32 row as a fused-multiply-add chain. One thread per row. level_nodes == null: row j
-// of `centroids` itself.
-__global__ void level_table_kernel(const float *centroids, const uint32_t *level_nodes, uint32_t n, uint32_t dim,
-                                         uint32_t kp, const float *mu, uint16_t *table, float *sqn) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+// norm of the f32 row. One wave per row; grid = ceil(n / 4), block 256. level_nodes == null: row j of
+// `centroids` itself.
+__global__ void __launch_bounds__(256)
+level_table_kernel(const float *centroids, const uint32_t *level_nodes, uint32_t n, uint32_t dim, uint32_t kp,
+                   const float *mu, uint16_t *table, float *sqn) {
+    const uint32_t j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= n) return;
     const float *c = centroids + (uint64_t)(level_nodes ? level_nodes[j] : j) * dim;
     uint16_t *t = table + (uint64_t)j * kp * 2;
     float s = 0.f;
-    for (uint32_t i = 0; i < dim; ++i) {
-        float v = c[i] - mu[i];
+    for (uint32_t i = lane; i < kp; i += 64) {
+        const float v = i < dim ? c[i] - mu[i] : 0.f;
         bf16_split_store(t, i, v);
         s = __builtin_fmaf(v, v, s);
     }
-    for (uint32_t i = dim; i < kp; ++i) bf16_split_store(t, i, 0.f);
-    sqn[j] = s;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) sqn[j] = s;
 }
 
 // q' = q - mu in split form and |q'|^2 for every query of the batch (one wave per query).
