@@ -16,7 +16,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 300 rocprofv3 --pmc $c -d /tmp/prof_$tag/$c -o p --output-format csv -- python3 "$root/bench.py" --config "$cfg" --no-cpu-baseline --steps 3 --warmup 1 "$@" > /dev/null 2>&1
   f=$(ls /tmp/prof_$tag/$c/*counter_collection.csv | head -1)
   head -1 "$f" > "$out/pmc_$c.csv"
-  grep "cuddle::" "$f" >> "$out/pmc_$c.csv" || true
+  grep "cuddle::" "$f" | grep -v "assign_gemm\|assign_finish\|level_table\|level_sum\|level_mean" >> "$out/pmc_$c.csv" || true  # search-path kernels only
 done
 cd "$root"
 python3 tools/pmc_traffic.py "$out/pmc_FETCH_SIZE.csv" "$out/pmc_WRITE_SIZE.csv" "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --config $cfg --no-cpu-baseline --steps 3 --warmup 1 $*" "$cfg" > "$out/pmc_hbm_traffic.json"

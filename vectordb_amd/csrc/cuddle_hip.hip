@@ -127,7 +127,7 @@ struct Plan {
     uint32_t kc_cap = 0;    // prefilter candidates per query (probes + margin)
     float *qsq = nullptr, *rc_dist = nullptr, *rc_max = nullptr;
     uint16_t *qcent = nullptr; // centred queries as bf16 (hi, lo) pairs
-    uint32_t *rc_pos = nullptr, *rflag = nullptr;
+    uint32_t *rc_pos = nullptr, *rflag = nullptr, *rc_cnt = nullptr;
     uint32_t *order = nullptr; // queries by decreasing candidate count
     size_t bytes = 0;
 };
@@ -640,7 +640,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     size_t o_sc = carve(qc * 4), o_cc = carve(qc * 4);
     pl.kc_cap = (uint32_t)align_up((size_t)pl.probes + route_margin(pl.probes), 32);
     size_t o_qcent = carve(qc * split_kp(v.dim) * 4), o_qsq = carve(qc * 4);
-    size_t o_rcp = carve(qc * pl.kc_cap * 4), o_rcd = carve(qc * pl.kc_cap * 4), o_rcm = carve(qc * 4), o_rfl = carve(qc * 4);
+    size_t o_rcp = carve(qc * pl.kc_cap * 4), o_rcd = carve(qc * pl.kc_cap * 4), o_rcm = carve(qc * 4), o_rfl = carve(qc * 4), o_rcc = carve(qc * 4);
     size_t o_ord = carve(qc * 4);
     const size_t gw = (size_t)ix->max_parent_width + 1;
     size_t o_pi = carve(qc * pl.probes * 4), o_pp = carve(qc * pl.probes * 4), o_ps = carve(qc * pl.probes * 4);
@@ -660,7 +660,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     pl.sel_count = (uint32_t *)(b + o_sc); pl.cand_count = (uint32_t *)(b + o_cc);
     pl.qcent = (uint16_t *)(b + o_qcent); pl.qsq = (float *)(b + o_qsq);
     pl.rc_pos = (uint32_t *)(b + o_rcp); pl.rc_dist = (float *)(b + o_rcd); pl.rc_max = (float *)(b + o_rcm);
-    pl.rflag = (uint32_t *)(b + o_rfl);
+    pl.rflag = (uint32_t *)(b + o_rfl); pl.rc_cnt = (uint32_t *)(b + o_rcc);
     pl.order = (uint32_t *)(b + o_ord);
     pl.pair_info = (uint32_t *)(b + o_pi); pl.pair_parent = (uint32_t *)(b + o_pp); pl.pair_sorted = (uint32_t *)(b + o_ps);
     pl.small_flag = (uint32_t *)(b + o_sf);
@@ -726,6 +726,25 @@ static void launch_query_norms(cuddle_index *ix, const Plan &pl, const float *dq
     hipLaunchKernelGGL(query_norm_kernel, dim3((nq * 4 + 255) / 256), dim3(256), 0, s, dq, nq, ix->dev.dim, pl.qnorm);
 }
 
+// Prefilter of the approximate distances in pl.fdist: keys in registers, as few per thread as the bound
+// on the frontier width allows (unused key slots still cost their predicated instructions in every pass).
+// ncount / skip / cand_cnt: per-query frontiers (see route_prefilter_reg_kernel).
+static void launch_prefilter(const Plan &pl, uint32_t nq, uint32_t n, uint32_t kc, const uint32_t *ncount, const uint32_t *skip,
+                             uint32_t *cand_cnt, hipStream_t s) {
+#define CUDDLE_PREFILTER(T, K)                                                                                                \
+    hipLaunchKernelGGL((route_prefilter_reg_kernel<T, K>), dim3(nq), dim3(T), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,    \
+                       pl.kc_cap, pl.rc_max, ncount, skip, cand_cnt)
+    if (n <= 128 * 8) CUDDLE_PREFILTER(128, 8);
+    else if (n <= 256 * 8) CUDDLE_PREFILTER(256, 8);
+    else if (n <= 256 * 16) CUDDLE_PREFILTER(256, 16);
+    else if (n <= 256 * 24) CUDDLE_PREFILTER(256, 24);
+    else if (n <= 512 * 16) CUDDLE_PREFILTER(512, 16);
+    else if (n <= 512 * 20) CUDDLE_PREFILTER(512, 20);
+    else if (n <= 512 * 24) CUDDLE_PREFILTER(512, 24);
+    else CUDDLE_PREFILTER(512, 32);
+#undef CUDDLE_PREFILTER
+}
+
 // Approximate distances of every query of the chunk to every node of a level that has contraction
 // operands: pl.fdist[q][0..g.n) and pl.qsq[q].
 static void launch_level_gemm(cuddle_index *ix, const Plan &pl, const LevelGemm &g, const float *dq, uint32_t nq, hipStream_t s) {
@@ -785,6 +804,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             continue;
         }
         const uint32_t *only = nullptr;
+        bool grouped_filter = false, grouped_finish = false;
+        uint32_t grouped_kc = 0;
         if (grouped) {
             // pairs recorded by the level above -> parent order -> one block per (parent, 8 queries)
             const uint32_t wprev = ix->level_width[l - 1], total = nq * pl.probes;
@@ -793,11 +814,36 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             hipLaunchKernelGGL(pair_fill_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pl.pair_info, pl.pair_parent, total,
                                pl.grp_poff, pl.grp_fill, pl.pair_sorted);
             const uint32_t items = (total + kGroupPairs - 1) / kGroupPairs + std::min(wprev, total);
-            const size_t glds = 2 * (size_t)kGroupNQ * ((v.dim + 3) & ~3u) * sizeof(float);
-            auto gk = grouped_kernel_for(v.dim, v.metric);
-            hipLaunchKernelGGL(gk, dim3(items), dim3(256), glds, s, v, dq, ix->lvl[l - 1].nodes, wprev, pl.grp_ioff,
-                               reinterpret_cast<const uint4 *>(pl.grp_item), pl.pair_sorted, pl.fdist, pl.fstride, pl.qnorm);
-            only = pl.small_flag; // queries with small frontiers: the exact kernel below, in their own arithmetic
+            static const bool no_filter = getenv("CUDDLE_GROUPED_EXACT") != nullptr; // tuning aid: exact distances for every pair
+            grouped_filter = !stats && g.n && bound <= 512 * 32 && !no_filter;
+            if (grouped_filter) {
+                // approximate distances of all pairs on the matrix cores, then the same prefilter / exact
+                // refinement / proof as on a shared level, per query; queries that are not grouped (small
+                // frontiers) or fail the proof are flagged for the exact kernels below
+                const uint32_t kp = split_kp(v.dim), kc = std::min(bound, pl.kc_cap);
+                hipLaunchKernelGGL(center_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, kp, pl.qcent, pl.qsq);
+                const dim3 ggrid(items, (ix->max_children + 63) / 64);
+                if (kp >= 512)
+                    hipLaunchKernelGGL(route_gemm_grouped_kernel<64>, ggrid, dim3(256), (route_gemm_lds_bytes<1, 64>()), s, v,
+                                       (const u32x4 *)pl.qcent, pl.qsq, (const u32x4 *)g.table, g.sqn, kp, ix->lvl[l - 1].nodes, wprev,
+                                       pl.grp_ioff, reinterpret_cast<const uint4 *>(pl.grp_item), pl.pair_sorted, pl.fdist, pl.fstride);
+                else
+                    hipLaunchKernelGGL(route_gemm_grouped_kernel<32>, ggrid, dim3(256), (route_gemm_lds_bytes<1, 32>()), s, v,
+                                       (const u32x4 *)pl.qcent, pl.qsq, (const u32x4 *)g.table, g.sqn, kp, ix->lvl[l - 1].nodes, wprev,
+                                       pl.grp_ioff, reinterpret_cast<const uint4 *>(pl.grp_item), pl.pair_sorted, pl.fdist, pl.fstride);
+                launch_prefilter(pl, nq, bound, kc, pl.fcount[cur], pl.small_flag, pl.rc_cnt, s);
+                hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
+                                   pl.frontier[cur], pl.rc_pos, pl.kc_cap, kc, pl.rc_dist, pl.qnorm, pl.fstride, pl.small_flag, pl.rc_cnt);
+                grouped_finish = true; // launched below, once this level's PairOut is known
+                grouped_kc = kc;
+                only = pl.rflag;
+            } else {
+                const size_t glds = 2 * (size_t)kGroupNQ * ((v.dim + 3) & ~3u) * sizeof(float);
+                auto gk = grouped_kernel_for(v.dim, v.metric);
+                hipLaunchKernelGGL(gk, dim3(items), dim3(256), glds, s, v, dq, ix->lvl[l - 1].nodes, wprev, pl.grp_ioff,
+                                   reinterpret_cast<const uint4 *>(pl.grp_item), pl.pair_sorted, pl.fdist, pl.fstride, pl.qnorm);
+                only = pl.small_flag; // queries with small frontiers: the exact kernel below, in their own arithmetic
+            }
         }
         // Will the next level evaluate per-query frontiers wider than probes? Then this level's
         // expansion also records its (query, chosen node) pairs, grouped by node for that level.
@@ -816,27 +862,20 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 HIP_TRY(hipMemsetAsync(pl.grp_cnt, 0, ((size_t)ix->level_width[l] + 1) * 4, s));
             }
         }
+        if (grouped_finish)
+            hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(grouped_kc), pl.probes), s,
+                               v, pl.frontier[cur], bound, pl.rc_pos, pl.rc_dist, pl.kc_cap, grouped_kc, pl.rc_max, pl.qsq, g.max_sqn,
+                               pl.probes, pl.frontier[cur ^ 1], pl.fstride, pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,
+                               pl.rflag, &ix->d_stats->fallbacks, po, pl.fcount[cur], pl.small_flag, pl.rc_cnt);
         const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound;
         if (use_gemm) {
             const uint32_t n = g.n, kc = std::min(n, pl.kc_cap);
             launch_level_gemm(ix, pl, g, dq, nq, s);
-#define CUDDLE_PREFILTER(T, K)                                                                                                \
-    hipLaunchKernelGGL((route_prefilter_reg_kernel<T, K>), dim3(nq), dim3(T), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,    \
-                       pl.kc_cap, pl.rc_max)
-            // keys in registers, as few per thread as the level's width allows (unused key slots still cost
-            // their predicated instructions in every pass)
-            if (n <= 128 * 8) CUDDLE_PREFILTER(128, 8);
-            else if (n <= 256 * 8) CUDDLE_PREFILTER(256, 8);
-            else if (n <= 256 * 16) CUDDLE_PREFILTER(256, 16);
-            else if (n <= 256 * 24) CUDDLE_PREFILTER(256, 24);
-            else if (n <= 512 * 16) CUDDLE_PREFILTER(512, 16);
-            else if (n <= 512 * 20) CUDDLE_PREFILTER(512, 20);
-            else if (n <= 512 * 24) CUDDLE_PREFILTER(512, 24);
-            else if (n <= 512 * 32) CUDDLE_PREFILTER(512, 32);
+            if (n <= 512 * 32)
+                launch_prefilter(pl, nq, n, kc, nullptr, nullptr, nullptr, s);
             else
                 hipLaunchKernelGGL(route_prefilter_kernel, dim3(nq), dim3(256), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,
                                    pl.kc_cap, pl.rc_max);
-#undef CUDDLE_PREFILTER
             hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                g.nodes, pl.rc_pos, pl.kc_cap, kc, pl.rc_dist, pl.qnorm);
             hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(kc), pl.probes), s,
@@ -848,7 +887,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         if (!keep_all) // after the MFMA or grouped path only the (rare) flagged queries do work here: few blocks per query
             hipLaunchKernelGGL(route_dist_kernel, dim3((use_gemm || grouped) ? 4 : std::min<uint32_t>((bound + 63) / 64, 64), nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                pl.frontier[cur], pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, only, pl.qnorm);
-        const uint32_t *sel_only = grouped ? nullptr : only; // after the grouped path every query still selects here
+        const uint32_t *sel_only = (grouped && !grouped_filter) ? nullptr : only; // after the exact grouped path every query still selects here
 #define CUDDLE_SELECT_REG(T, K)                                                                                              \
     hipLaunchKernelGGL((route_select_reg_kernel<T, K>), dim3(nq), dim3(T), route_select_reg_lds_bytes(scap), s, v, pl.frontier[cur], \
                        pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, scap,                                    \

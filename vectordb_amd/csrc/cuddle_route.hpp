@@ -776,11 +776,12 @@ constexpr size_t route_gemm_lds_bytes() { return (size_t)(kGemmBM + 64 * NT) * (
 // out: [M][ostride]. grid = 8 * ceil(gy / rg) * ceil(gx / (8 / rg)).
 // One block tile of the contraction: acc + cor = A[by tile] * B[bx tile]^T (see route_gemm_kernel for
 // the layouts). smem: route_gemm_lds_bytes<NT, BK>() bytes; starts with a barrier, so the caller may
-// have used the LDS for something else before. All 256 threads call.
+// have used the LDS for something else before. arow != null: the tile's 128 rows of A are the rows
+// arow[0..128) (an LDS table; by and M are not used). All 256 threads call.
 template <int NT, int BK>
 __device__ __forceinline__ void split_gemm_tile(const u32x4 *A, const u32x4 *B, uint32_t M, uint32_t N, uint32_t kp,
                                                 uint32_t by, uint32_t bx, unsigned char *smem, f32x16 (&acc)[2][NT],
-                                                f32x16 (&cor)[2][NT]) {
+                                                f32x16 (&cor)[2][NT], const uint32_t *arow = nullptr) {
     constexpr int BN = 64 * NT, CH = BK / 4, RS = CH + 1, RPP = 256 / CH, PA = kGemmBM / RPP, PB = BN / RPP;
     u32x4 *As = reinterpret_cast<u32x4 *>(smem); // [128][RS]
     u32x4 *Bs = As + kGemmBM * RS;               // [BN][RS]
@@ -789,7 +790,8 @@ __device__ __forceinline__ void split_gemm_tile(const u32x4 *A, const u32x4 *B, 
     const uint32_t lr = tid / CH, c = tid % CH, rowu = kp / 4; // 16-byte units per split row
     const u32x4 *ga[PA], *gb[PB];
 #pragma unroll
-    for (int i = 0; i < PA; ++i) ga[i] = A + (uint64_t)min(by * kGemmBM + lr + RPP * i, M - 1) * rowu + c;
+    for (int i = 0; i < PA; ++i)
+        ga[i] = A + (uint64_t)(arow ? arow[lr + RPP * i] : min(by * kGemmBM + lr + RPP * i, M - 1)) * rowu + c;
 #pragma unroll
     for (int i = 0; i < PB; ++i) gb[i] = B + (uint64_t)min(bx * BN + lr + RPP * i, N - 1) * rowu + c;
     u32x4 pa[PA], pb[PB];
@@ -890,6 +892,52 @@ route_gemm_kernel(const u32x4 *A, const float *Asq, const u32x4 *B, const float 
         }
 }
 
+// The same contraction for a level whose frontiers differ per query: one block per (work item of
+// pair_scan_kernel = a parent node and up to kGroupPairs of the queries that chose it, column tile of
+// 64 of the parent's children). A rows are gathered by query; B rows are the children's rows of the
+// level table, contiguous because the level is laid out breadth-first. d~ goes where the grouped
+// exact kernel puts d: fdist[query][position of the parent's first child in the query's frontier + child].
+// grid = (bound on the items, ceil(max children / 64)), block 256, LDS route_gemm_lds_bytes<1, BK>().
+template <int BK>
+__global__ void __launch_bounds__(256, 3)
+route_gemm_grouped_kernel(IndexDev ix, const u32x4 *A, const float *Asq, const u32x4 *B, const float *Bsq, uint32_t kp,
+                          const uint32_t *level_nodes, uint32_t n_parents, const uint32_t *ioff, const uint4 *items,
+                          const uint32_t *sorted, float *fdist, uint32_t fstride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t pk[kGemmBM], arow[kGemmBM];
+    const uint32_t item = blockIdx.x, bx = blockIdx.y;
+    const uint32_t n_items = ioff[n_parents];
+    const uint4 rec = items[min(item, max(n_items, 1u) - 1)];
+    if (item >= n_items) return;
+    const uint32_t p = rec.x, pb = rec.y, np = rec.z;
+    const uint32_t node = level_nodes[p];
+    const uint32_t cb = ix.child_off[node], cc = ix.child_off[node + 1] - cb;
+    if (bx * 64 >= cc) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t wr = w >> 1, wc = w & 1, r = lane & 31, h = lane >> 5;
+    const uint32_t cpos0 = ix.level_pos[ix.children[cb]]; // row of the first child in the level table
+    if (tid < kGemmBM) {
+        const uint32_t v = sorted[pb + min(tid, np - 1)]; // unused rows repeat the last pair
+        pk[tid] = v;
+        arow[tid] = v >> kPairOffBits;
+    }
+    __syncthreads();
+    f32x16 acc[2][1], cor[2][1];
+    split_gemm_tile<1, BK>(A, B + (uint64_t)cpos0 * (kp / 4), 0, cc, kp, 0, bx, smem, acc, cor, arow);
+    const uint32_t gn = bx * 64 + wc * 32 + r;
+    if (gn >= cc) return;
+    const float bs = Bsq[cpos0 + gn];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t lrow = wr * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (lrow >= np) continue;
+            const uint32_t v = pk[lrow], q = v >> kPairOffBits, off = v & ((1u << kPairOffBits) - 1);
+            fdist[(uint64_t)q * fstride + off + gn] = approx_distance(ix.metric, acc[mt][0][e] + cor[mt][0][e], Asq[q], bs);
+        }
+}
+
 // Bound on |d~ - d| (d = the exact-order f32 distance) for one query against any node of the
 // level: any-order f32 dot products of length D are within gamma_D * sum|x_i y_i| of the true
 // value, the exact-order L2 within gamma_(D/16+8) of it, centring adds u-relative component
@@ -956,14 +1004,24 @@ route_prefilter_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_
 // same for every key are skipped: no counting, no same-address atomics), then the remaining
 // passes from registers; the winners are written in any order (which ties at the threshold are
 // kept is free: every unselected node still has d~ >= cand_max, which is all the proof needs).
+// ncount != null: per-query frontiers of ncount[q] nodes (at most n); queries with skip[q] != 0 are
+// left alone; cand_cnt[q] = the query's number of candidates, min(kc, ncount[q]).
 template <int THREADS, int KPT>
 __global__ void __launch_bounds__(THREADS)
 route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_t kc, uint32_t *cand_pos,
-                           uint32_t cstride, float *cand_max) {
+                           uint32_t cstride, float *cand_max, const uint32_t *ncount = nullptr,
+                           const uint32_t *skip = nullptr, uint32_t *cand_cnt = nullptr) {
     __shared__ uint32_t hist[4 * 256];
     __shared__ uint32_t misc[4];
     __shared__ uint32_t wred[2 * (THREADS / 64)];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    if (skip && skip[q]) return;
+    if (ncount) { // per-query frontier: its own width, and no more candidates than it has nodes
+        n = min(n, ncount[q]);
+        kc = min(kc, n);
+        if (tid == 0) cand_cnt[q] = kc;
+        if (n == 0) return;
+    }
     const float *fd = fdist + (uint64_t)q * fstride;
     uint32_t keys[KPT];
 #pragma unroll
@@ -994,13 +1052,22 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
 
 // Exact distance(query, centroid, metric) of the prefiltered nodes (levels on this path hold more
 // than 100 nodes, so search() uses distance() for them, hierarchical.rs:355-365).
+// cand_cnt != null: per-query frontiers (level_nodes = the frontier array, fstride per query) with
+// cand_cnt[q] candidates; queries with skip[q] != 0 are left alone.
 // grid = (ceil(kc/64), nq), block 256: one 4-lane group per (query, candidate).
 __global__ void __launch_bounds__(256)
 route_refine_kernel(IndexDev ix, const float *queries, const uint32_t *level_nodes, const uint32_t *cand_pos,
-                    uint32_t cstride, uint32_t kc, float *cand_dist, const float *qnorm) {
+                    uint32_t cstride, uint32_t kc, float *cand_dist, const float *qnorm, uint32_t fstride = 0,
+                    const uint32_t *skip = nullptr, const uint32_t *cand_cnt = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);
     const uint32_t q = blockIdx.y, D = ix.dim;
+    if (skip && skip[q]) return;
+    if (cand_cnt) { // per-query frontiers: level_nodes is the array of frontiers, fstride nodes per query
+        kc = cand_cnt[q];
+        level_nodes += (uint64_t)q * fstride;
+        if (blockIdx.x * 64 >= kc) return;
+    }
     const float *qg = queries + (uint64_t)q * D;
     for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) qs[i] = qg[i];
     __syncthreads();
@@ -1020,17 +1087,30 @@ inline size_t route_finish_lds_bytes(uint32_t kpad, uint32_t probes) {
 // are the exact selection provided no unselected node can beat the probes-th one:
 //     cand_max - error_bound > exact distance of the probes-th      (or every node was a candidate).
 // Then expand as route_select_kernel does. Otherwise raise flag[q] for the exact path.
+// cand_cnt != null: per-query frontiers (level_nodes = the frontier array, fstride per query) of
+// ncount[q] nodes with cand_cnt[q] >= probes candidates; kc = the largest candidate count (LDS size).
+// Queries with skip[q] != 0 are flagged for the exact path without being counted as fallbacks.
 // One block per query; dynamic LDS = route_finish_lds_bytes(next_pow2(kc), probes).
 __global__ void __launch_bounds__(256)
 route_finish_kernel(IndexDev ix, const uint32_t *level_nodes, uint32_t n, const uint32_t *cand_pos,
                     const float *cand_dist, uint32_t cstride, uint32_t kc, const float *cand_max, const float *qsq,
                     float max_csq, uint32_t probes, uint32_t *next_frontier, uint32_t fstride, uint32_t *next_fcount,
-                    uint32_t *leaves, uint32_t lstride, uint32_t *lcount, uint32_t *flag, uint32_t *fallbacks, PairOut po) {
+                    uint32_t *leaves, uint32_t lstride, uint32_t *lcount, uint32_t *flag, uint32_t *fallbacks, PairOut po,
+                    const uint32_t *ncount = nullptr, const uint32_t *skip = nullptr, const uint32_t *cand_cnt = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t kpad = next_pow2(kc);
     uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);
     uint32_t *xs = reinterpret_cast<uint32_t *>(skeys + kpad);
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    if (skip && skip[q]) { // not on this path (small frontier): the exact kernels take the query
+        if (tid == 0) flag[q] = 1;
+        return;
+    }
+    if (cand_cnt) { // per-query frontiers: level_nodes is the array of frontiers, fstride nodes per query
+        n = ncount[q];
+        kc = cand_cnt[q];
+        level_nodes += (uint64_t)q * fstride;
+    }
     for (uint32_t i = tid; i < kpad; i += blockDim.x)
         skeys[i] = i < kc ? (((uint64_t)f32_key(cand_dist[(uint64_t)q * cstride + i]) << 32) | cand_pos[(uint64_t)q * cstride + i])
                           : ~0ull;
