@@ -136,6 +136,7 @@ struct Plan {
 struct LevelGemm {
     uint32_t n = 0;            // 0: contraction operands not built for this level
     uint32_t *nodes = nullptr; // [level width] node ids, breadth-first order (every level has it)
+    uint2 *child_rows = nullptr; // [level width] (position of the node's first child in the next level, children)
     uint16_t *table = nullptr; // [n][split_kp(dim)] centroid - mu as bf16 (hi, lo) pairs, see level_table_kernel
     float *sqn = nullptr;      // [n]
     float *mu = nullptr;       // [dim]
@@ -436,6 +437,15 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
         uint32_t *lp;
         ST_TRY(upload(ix, level_pos.data(), (size_t)n, &lp));
         v.level_pos = lp;
+        std::vector<uint2> rows;
+        for (uint32_t l = 0; l + 1 < n_levels; ++l) { // children of one node are consecutive in the next level
+            rows.assign(level_nodes[l].size(), make_uint2(0u, 0u));
+            for (size_t i = 0; i < level_nodes[l].size(); ++i) {
+                const uint32_t v2 = level_nodes[l][i], cb = d->child_offsets[v2], cc = d->child_offsets[v2 + 1] - cb;
+                rows[i] = make_uint2(cc ? level_pos[d->children[cb]] : 0u, cc);
+            }
+            ST_TRY(upload(ix, rows.data(), rows.size(), &ix->lvl[l].child_rows));
+        }
     }
     { // operands of the MFMA contraction for every level wide enough to use it
         for (uint32_t l = 0; l < n_levels; ++l) {
@@ -809,28 +819,25 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         if (grouped) {
             // pairs recorded by the level above -> parent order -> one block per (parent, 8 queries)
             const uint32_t wprev = ix->level_width[l - 1], total = nq * pl.probes;
+            static const bool no_filter = getenv("CUDDLE_GROUPED_EXACT") != nullptr; // tuning aid: exact distances for every pair
+            grouped_filter = !stats && g.n && bound <= 512 * 32 && !no_filter;
             hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, pl.grp_cnt, wprev, pl.grp_poff, pl.grp_ioff, pl.grp_fill,
-                               reinterpret_cast<uint4 *>(pl.grp_item));
+                               reinterpret_cast<uint4 *>(pl.grp_item), grouped_filter ? ix->lvl[l - 1].child_rows : nullptr);
             hipLaunchKernelGGL(pair_fill_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pl.pair_info, pl.pair_parent, total,
                                pl.grp_poff, pl.grp_fill, pl.pair_sorted);
             const uint32_t items = (total + kGroupPairs - 1) / kGroupPairs + std::min(wprev, total);
-            static const bool no_filter = getenv("CUDDLE_GROUPED_EXACT") != nullptr; // tuning aid: exact distances for every pair
-            grouped_filter = !stats && g.n && bound <= 512 * 32 && !no_filter;
             if (grouped_filter) {
                 // approximate distances of all pairs on the matrix cores, then the same prefilter / exact
                 // refinement / proof as on a shared level, per query; queries that are not grouped (small
                 // frontiers) or fail the proof are flagged for the exact kernels below
                 const uint32_t kp = split_kp(v.dim), kc = std::min(bound, pl.kc_cap);
                 hipLaunchKernelGGL(center_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, kp, pl.qcent, pl.qsq);
-                const dim3 ggrid(items, (ix->max_children + 63) / 64);
-                if (kp >= 512)
-                    hipLaunchKernelGGL(route_gemm_grouped_kernel<64>, ggrid, dim3(256), (route_gemm_lds_bytes<1, 64>()), s, v,
-                                       (const u32x4 *)pl.qcent, pl.qsq, (const u32x4 *)g.table, g.sqn, kp, ix->lvl[l - 1].nodes, wprev,
-                                       pl.grp_ioff, reinterpret_cast<const uint4 *>(pl.grp_item), pl.pair_sorted, pl.fdist, pl.fstride);
-                else
-                    hipLaunchKernelGGL(route_gemm_grouped_kernel<32>, ggrid, dim3(256), (route_gemm_lds_bytes<1, 32>()), s, v,
-                                       (const u32x4 *)pl.qcent, pl.qsq, (const u32x4 *)g.table, g.sqn, kp, ix->lvl[l - 1].nodes, wprev,
-                                       pl.grp_ioff, reinterpret_cast<const uint4 *>(pl.grp_item), pl.pair_sorted, pl.fdist, pl.fstride);
+#define CUDDLE_GROUPED_GEMM(KC)                                                                                              \
+    hipLaunchKernelGGL(route_gemm_grouped_kernel<KC>, dim3(items), dim3(256), (route_gemm_grouped_lds_bytes<KC>()), s, v,       \
+                       (const u32x4 *)pl.qcent, pl.qsq, (const u32x4 *)g.table, g.sqn, kp, wprev, pl.grp_ioff,                  \
+                       reinterpret_cast<const uint4 *>(pl.grp_item), pl.pair_sorted, pl.fdist, pl.fstride)
+                CUDDLE_GROUPED_GEMM(64); // K chunk: 32 and 64 measured alike, 128 slower (fewer blocks in flight)
+#undef CUDDLE_GROUPED_GEMM
                 launch_prefilter(pl, nq, bound, kc, pl.fcount[cur], pl.small_flag, pl.rc_cnt, s);
                 hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                    pl.frontier[cur], pl.rc_pos, pl.kc_cap, kc, pl.rc_dist, pl.qnorm, pl.fstride, pl.small_flag, pl.rc_cnt);

@@ -452,10 +452,12 @@ route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride,
 // smaller frontiers are not grouped (PairOut::small).
 
 // Exclusive prefix sums over the per-parent pair counts: poff = pairs, ioff = work items (blocks of
-// up to kGroupPairs pairs of one parent); items[item] = (parent, first pair, pairs, 0); also clears
-// the fill counters. One block of 1024 threads; the per-parent arrays hold n + 1 entries.
+// up to kGroupPairs pairs of one parent); items[item] = (parent, first pair, pairs, 0), or, with
+// child_rows (per parent: table row of its first child, number of children) given, (first pair,
+// pairs, row, children) for route_gemm_grouped_kernel; also clears the fill counters. One block of 1024 threads; the per-parent arrays hold n + 1 entries.
 __global__ void __launch_bounds__(1024)
-pair_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *poff, uint32_t *ioff, uint32_t *fill, uint4 *items) {
+pair_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *poff, uint32_t *ioff, uint32_t *fill, uint4 *items,
+                 const uint2 *child_rows) {
     __shared__ uint32_t sp[1024], si[1024];
     const uint32_t tid = threadIdx.x, per = (n + 1023) / 1024;
     const uint32_t b = min(tid * per, n), e = min(b + per, n);
@@ -480,8 +482,11 @@ pair_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *poff, uint32_t *ioff
         poff[i] = rp;
         ioff[i] = ri;
         fill[i] = 0;
-        for (uint32_t t = 0; t < ni; ++t)
-            items[ri + t] = make_uint4(i, rp + t * kGroupPairs, min((uint32_t)kGroupPairs, c - t * kGroupPairs), 0u);
+        const uint2 cr = child_rows ? child_rows[i] : make_uint2(0u, 0u);
+        for (uint32_t t = 0; t < ni; ++t) {
+            const uint32_t first = rp + t * kGroupPairs, np = min((uint32_t)kGroupPairs, c - t * kGroupPairs);
+            items[ri + t] = child_rows ? make_uint4(first, np, cr.x, cr.y) : make_uint4(i, first, np, 0u);
+        }
         rp += c;
         ri += ni;
     }
@@ -892,50 +897,105 @@ route_gemm_kernel(const u32x4 *A, const float *Asq, const u32x4 *B, const float 
         }
 }
 
-// The same contraction for a level whose frontiers differ per query: one block per (work item of
-// pair_scan_kernel = a parent node and up to kGroupPairs of the queries that chose it, column tile of
-// 64 of the parent's children). A rows are gathered by query; B rows are the children's rows of the
-// level table, contiguous because the level is laid out breadth-first. d~ goes where the grouped
-// exact kernel puts d: fdist[query][position of the parent's first child in the query's frontier + child].
-// grid = (bound on the items, ceil(max children / 64)), block 256, LDS route_gemm_lds_bytes<1, BK>().
-template <int BK>
-__global__ void __launch_bounds__(256, 3)
+// The same contraction for a level whose frontiers differ per query: one block per work item of
+// pair_scan_kernel = a parent node and up to kGroupPairs (64) of the queries that chose it. A rows are
+// gathered by query; B rows are the children's rows of the level table, contiguous because the level
+// is laid out breadth-first. d~ goes where the grouped exact kernel puts d:
+// fdist[query][position of the parent's first child in the query's frontier + child].
+// These are small problems (64 x <= a few hundred x K) and there are thousands of them, so a block's
+// time is load latency, not arithmetic: the block keeps a 64-row A chunk and a 64-row B chunk of KC
+// values in LDS (small, so that many blocks are in flight per CU), walks the parent's children in
+// tiles of 64, and fetches the next chunk while the matrix cores work on the current one. 4 waves as
+// 2 x 2, each one 32 x 32 MFMA tile (two accumulators, see split_gemm_tile).
+// grid = bound on the items, block 256, LDS route_gemm_grouped_lds_bytes<KC>(). kp a multiple of KC.
+template <int KC>
+constexpr size_t route_gemm_grouped_lds_bytes() { return (size_t)2 * 64 * (KC / 4 + 1) * 16; }
+
+template <int KC>
+__global__ void __launch_bounds__(256, 2)
 route_gemm_grouped_kernel(IndexDev ix, const u32x4 *A, const float *Asq, const u32x4 *B, const float *Bsq, uint32_t kp,
-                          const uint32_t *level_nodes, uint32_t n_parents, const uint32_t *ioff, const uint4 *items,
-                          const uint32_t *sorted, float *fdist, uint32_t fstride) {
+                          uint32_t n_parents, const uint32_t *ioff, const uint4 *items, const uint32_t *sorted, float *fdist,
+                          uint32_t fstride) {
+    constexpr int CHU = KC / 4, RS = CHU + 1, U = CHU / 4; // 16-byte units per chunk row; LDS row stride; units per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t pk[kGemmBM], arow[kGemmBM];
-    const uint32_t item = blockIdx.x, bx = blockIdx.y;
+    u32x4 *As = reinterpret_cast<u32x4 *>(smem); // [64][RS]
+    u32x4 *Bs = As + 64 * RS;                    // [64][RS]
+    __shared__ uint32_t pk[64];
+    __shared__ float pasq[64]; // squared norms of the pairs' queries
+    const uint32_t item = blockIdx.x;
     const uint32_t n_items = ioff[n_parents];
     const uint4 rec = items[min(item, max(n_items, 1u) - 1)];
     if (item >= n_items) return;
-    const uint32_t p = rec.x, pb = rec.y, np = rec.z;
-    const uint32_t node = level_nodes[p];
-    const uint32_t cb = ix.child_off[node], cc = ix.child_off[node + 1] - cb;
-    if (bx * 64 >= cc) return;
+    CUDDLE_STAMP(7, 0);
+    const uint32_t pb = rec.x, np = rec.y, cpos0 = rec.z, cc = rec.w; // (pair_scan_kernel's contraction form)
+    if (cc == 0) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t wr = w >> 1, wc = w & 1, r = lane & 31, h = lane >> 5;
-    const uint32_t cpos0 = ix.level_pos[ix.children[cb]]; // row of the first child in the level table
-    if (tid < kGemmBM) {
-        const uint32_t v = sorted[pb + min(tid, np - 1)]; // unused rows repeat the last pair
-        pk[tid] = v;
-        arow[tid] = v >> kPairOffBits;
+    const uint32_t lrow = tid >> 2, lu = tid & 3, rowu = kp / 4, nchunks = kp / KC;
+    const uint32_t mypair = sorted[pb + min(lrow, np - 1)]; // unused rows repeat the last pair
+    if (lu == 0) {
+        pk[lrow] = mypair;
+        pasq[lrow] = Asq[mypair >> kPairOffBits];
     }
-    __syncthreads();
-    f32x16 acc[2][1], cor[2][1];
-    split_gemm_tile<1, BK>(A, B + (uint64_t)cpos0 * (kp / 4), 0, cc, kp, 0, bx, smem, acc, cor, arow);
-    const uint32_t gn = bx * 64 + wc * 32 + r;
-    if (gn >= cc) return;
-    const float bs = Bsq[cpos0 + gn];
+    const u32x4 *ga = A + (uint64_t)(mypair >> kPairOffBits) * rowu + lu;
+    const u32x4 *Bp = B + (uint64_t)cpos0 * rowu + lu;
+    u32x4 pa[U], pbv[U];
+    const uint32_t ntiles = (cc + 63) / 64, steps = ntiles * nchunks;
+    auto fetch = [&](uint32_t step) { // step = column tile * nchunks + chunk
+        const uint32_t bx = step / nchunks, ch = step - bx * nchunks;
+        const u32x4 *gb = Bp + (uint64_t)min(bx * 64 + lrow, cc - 1) * rowu + ch * CHU;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+        for (int j = 0; j < U; ++j) pbv[j] = gb[4 * j];
+        if (nchunks > 1 || step == 0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const uint32_t lrow = wr * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (lrow >= np) continue;
-            const uint32_t v = pk[lrow], q = v >> kPairOffBits, off = v & ((1u << kPairOffBits) - 1);
-            fdist[(uint64_t)q * fstride + off + gn] = approx_distance(ix.metric, acc[mt][0][e] + cor[mt][0][e], Asq[q], bs);
+            for (int j = 0; j < U; ++j) pa[j] = ga[ch * CHU + 4 * j];
         }
+    };
+    f32x16 acc, cor;
+    fetch(0);
+    for (uint32_t step = 0; step < steps; ++step) {
+        const uint32_t bx = step / nchunks, ch = step - bx * nchunks;
+        if (ch == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = cor[e] = 0.f;
+        }
+        __syncthreads(); // the previous step's LDS reads are done (first step: pk written)
+#pragma unroll
+        for (int j = 0; j < U; ++j) Bs[lrow * RS + lu + 4 * j] = pbv[j];
+        if (nchunks > 1 || step == 0) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) As[lrow * RS + lu + 4 * j] = pa[j];
+        }
+        __syncthreads();
+        if (step == 0) CUDDLE_STAMP(7, 1);
+        if (step + 1 < steps) fetch(step + 1);
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const uint32_t g = 2 * (2 * ks + h);
+            const u32x4 *pa4 = As + (wr * 32 + r) * RS + g, *pb4 = Bs + (wc * 32 + r) * RS + g;
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, pa4[0]), al = __builtin_bit_cast(bf16x8, pa4[1]);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, pb4[0]), bl = __builtin_bit_cast(bf16x8, pb4[1]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, cor, 0, 0, 0);
+            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, cor, 0, 0, 0);
+        }
+        if (step == 0) CUDDLE_STAMP(7, 2);
+        if (ch + 1 == nchunks) { // the tile is complete: C/D layout col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+            const uint32_t gn = bx * 64 + wc * 32 + r;
+            if (gn < cc) {
+                const float bs = Bsq[cpos0 + gn];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t prow = wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (prow >= np) continue;
+                    const uint32_t v = pk[prow], q = v >> kPairOffBits, off = v & ((1u << kPairOffBits) - 1);
+                    fdist[(uint64_t)q * fstride + off + gn] = approx_distance(ix.metric, acc[e] + cor[e], pasq[prow], bs);
+                }
+            }
+        }
+        if (step == 0) CUDDLE_STAMP(7, 3);
+    }
+    CUDDLE_STAMP(7, 4);
 }
 
 // Bound on |d~ - d| (d = the exact-order f32 distance) for one query against any node of the
