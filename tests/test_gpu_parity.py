@@ -163,3 +163,30 @@ def test_rabitq_search_matches_oracle(gpu, metric, d):
         assert np.array_equal(spos[i, :scnt[i]], t["sel_pos"])
         assert np.array_equal(skey[i, :scnt[i]], t["sel_key"])
         assert np.array_equal(sdist[i, :scnt[i]].view(np.uint32), t["sel_dist"].view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_mfma_routing_with_massive_ties(gpu, metric):
+    """Data with few distinct points: a wide level whose centroids repeat, so most approximate (and
+    exact) distances of a query tie. The prefilter's shortlist overflows and falls back to the plain
+    selection, the proof fails for tied boundaries and those queries take the exact kernels; the leaf
+    lists must still equal the all-exact path's and the oracle's."""
+    orc = _oracle()
+    rng = np.random.default_rng(17)
+    x = rng.integers(0, 2, (60000, 12)).astype(np.float32) + 0.001 * rng.standard_normal((60000, 12)).astype(np.float32)
+    x[::3] = np.round(x[::3])  # a third of the points exactly on the 4096 corners
+    from vectordb_amd.builder import build_index
+    fi = build_index(x, 100, 30, metric, 6, seed=4)
+    dev = DeviceIndex(fi, gpu)
+    q = np.round(queries_like(x, 120, 8, noise=0.0)).astype(np.float32)  # queries on corners: many exactly equal distances
+    for probes in (20, 100):
+        lv_mfma, lc_mfma = dev.route_batch(q, probes)
+        lv_exact, lc_exact = dev.route_batch(q, probes, _ffi.SEARCH_ROUTE_EXACT_ONLY)
+        assert np.array_equal(lc_mfma, lc_exact)
+        for i in range(q.shape[0]):
+            assert np.array_equal(lv_mfma[i, :lc_mfma[i]], lv_exact[i, :lc_exact[i]]), (probes, i)
+        oi = orc.OracleIndex(fi)
+        for i in range(0, q.shape[0], 9):
+            t = oi.search(q[i], 10, probes, 5, trace=True)
+            assert np.array_equal(lv_mfma[i, :lc_mfma[i]], t["leaves"]), (probes, i)
+    _compare_full(fi, dev, q[:30], 10, 100, 5)
