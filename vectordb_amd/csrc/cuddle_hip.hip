@@ -891,8 +891,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                                pl.rflag, &ix->d_stats->fallbacks, po);
             only = pl.rflag; // queries whose selection could not be proven exact fall through to the exact kernels
         }
-        if (!keep_all) // after the MFMA or grouped path only the (rare) flagged queries do work here: few blocks per query
-            hipLaunchKernelGGL(route_dist_kernel, dim3((use_gemm || grouped) ? 4 : std::min<uint32_t>((bound + 63) / 64, 64), nq), dim3(256), v.dim * sizeof(float), s, v, dq,
+        if (!keep_all) // after a filter path only the (rare) flagged queries do work here: one block per query; after the exact grouped path the small frontiers
+            hipLaunchKernelGGL(route_dist_kernel, dim3((use_gemm || grouped_filter) ? 1 : grouped ? 4 : std::min<uint32_t>((bound + 63) / 64, 64), nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                pl.frontier[cur], pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, only, pl.qnorm);
         const uint32_t *sel_only = (grouped && !grouped_filter) ? nullptr : only; // after the exact grouped path every query still selects here
 #define CUDDLE_SELECT_REG(T, K)                                                                                              \

@@ -1096,7 +1096,9 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
     // keys pass it. Selecting among the THREADS minima and then among that shortlist costs two cheap
     // selections instead of counting sweeps over all the keys.
     constexpr uint32_t SHORT = 2 * THREADS;
-    __shared__ uint32_t skey[KPT >= 8 ? SHORT : 1], sidx[KPT >= 8 ? SHORT : 1];
+    __shared__ uint32_t skey[KPT >= 8 ? SHORT : 1];
+    uint32_t T = 0, budget = 0;
+    bool have = false;
     if (KPT >= 8 && kc * 2 <= min(n, (uint32_t)THREADS)) { // (then about 1.4 kc keys pass T0)
         uint32_t lmin[1] = {keys[0]};
 #pragma unroll
@@ -1108,45 +1110,27 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
             for (int t = 0; t < KPT; ++t)
                 if (keys[t] <= T0 && (uint32_t)t * THREADS + tid < n) {
                     const uint32_t slot = atomicAdd(&misc[1], 1u);
-                    if (slot < SHORT) {
-                        skey[slot] = keys[t];
-                        sidx[slot] = t * THREADS + tid;
-                    }
+                    if (slot < SHORT) skey[slot] = keys[t];
                 }
         }
         __syncthreads(); // also: every wave is done with the first selection's counters
         const uint32_t m = misc[1];
         if (m <= SHORT) { // (more: many equal keys; the plain selection below handles any input)
-            uint32_t k2[2], i2[2];
+            uint32_t k2[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const uint32_t j = t * THREADS + tid;
                 k2[t] = j < m ? skey[j] : 0xFFFFFFFFu;
-                i2[t] = j < m ? sidx[j] : 0u;
             }
-            uint32_t budget;
-            const uint32_t T = reg_radix_select<THREADS, 2>(k2, m, kc, hist, wred, budget);
-            const uint32_t n_lt = kc - budget;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if ((uint32_t)t * THREADS + tid < m) {
-                    if (k2[t] < T) {
-                        const uint32_t slot = atomicAdd(&misc[2], 1u);
-                        if (slot < cstride) cp[slot] = i2[t];
-                    } else if (k2[t] == T) {
-                        const uint32_t ts = atomicAdd(&misc[3], 1u);
-                        if (ts < budget && n_lt + ts < cstride) cp[n_lt + ts] = i2[t];
-                    }
-                }
-            }
-            if (tid == 0) cand_max[q] = f32_from_key(T);
-            return;
+            T = reg_radix_select<THREADS, 2>(k2, m, kc, hist, wred, budget);
+            have = true;
         }
-        __syncthreads(); // the counters below are reused
+        __syncthreads(); // the selection's counters may be reused below
     }
-    uint32_t want;
-    const uint32_t prefix = reg_radix_select<THREADS, KPT>(keys, n, kc, hist, wred, want);
-    const uint32_t T = prefix, budget = want, n_lt = kc - budget;
+    if (!have) T = reg_radix_select<THREADS, KPT>(keys, n, kc, hist, wred, budget);
+    // winners from the registers, i.e. roughly in level order: neighbouring candidates are neighbouring
+    // rows of the centroid array, which the exact refinement reads next
+    const uint32_t n_lt = kc - budget;
 #pragma unroll
     for (int t = 0; t < KPT; ++t) {
         const uint32_t i = t * THREADS + tid;
