@@ -648,7 +648,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     size_t o_gd = carve(qc * (size_t)pl.cstride * 4); // u8/u16 Hamming or f32 estimates
     size_t o_sp = carve(qc * pl.sstride * 4), o_sk = carve(qc * pl.sstride * 4), o_sd = carve(qc * pl.sstride * 4);
     size_t o_sc = carve(qc * 4), o_cc = carve(qc * 4);
-    pl.kc_cap = (uint32_t)align_up((size_t)pl.probes + route_margin(pl.probes), 32);
+    pl.kc_cap = (uint32_t)align_up((size_t)pl.probes + route_margin(pl.probes), 4); // every candidate costs an exact distance
     size_t o_qcent = carve(qc * split_kp(v.dim) * 4), o_qsq = carve(qc * 4);
     size_t o_rcp = carve(qc * pl.kc_cap * 4), o_rcd = carve(qc * pl.kc_cap * 4), o_rcm = carve(qc * 4), o_rfl = carve(qc * 4), o_rcc = carve(qc * 4);
     size_t o_ord = carve(qc * 4);
