@@ -115,7 +115,7 @@ struct Plan {
     uint32_t *leaves = nullptr, *lcount = nullptr;
     uint16_t *gdist = nullptr;
     // (query, parent) pairs of the grouped routing level
-    uint32_t *pair_info = nullptr, *pair_parent = nullptr, *pair_sorted = nullptr, *small_flag = nullptr;
+    uint32_t *pair_info = nullptr, *pair_parent = nullptr, *pair_slot = nullptr, *pair_sorted = nullptr, *small_flag = nullptr;
     uint32_t *grp_cnt = nullptr, *grp_poff = nullptr, *grp_ioff = nullptr, *grp_fill = nullptr, *grp_item = nullptr;
     // leaf-sharded exact selection: threshold/budget per query, global order key of every selected candidate
     uint32_t *thr = nullptr;
@@ -653,7 +653,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     size_t o_rcp = carve(qc * pl.kc_cap * 4), o_rcd = carve(qc * pl.kc_cap * 4), o_rcm = carve(qc * 4), o_rfl = carve(qc * 4), o_rcc = carve(qc * 4);
     size_t o_ord = carve(qc * 4);
     const size_t gw = (size_t)ix->max_parent_width + 1;
-    size_t o_pi = carve(qc * pl.probes * 4), o_pp = carve(qc * pl.probes * 4), o_ps = carve(qc * pl.probes * 4);
+    size_t o_pi = carve(qc * pl.probes * 4), o_pp = carve(qc * pl.probes * 4), o_ps = carve(qc * pl.probes * 4), o_pl = carve(qc * pl.probes * 4);
     size_t o_sf = carve(qc * 4), o_gc = carve(gw * 4), o_gp = carve(gw * 4), o_gi = carve(gw * 4), o_gf = carve(gw * 4);
     size_t o_git = carve((qc * pl.probes / kGroupPairs + gw + 1) * 16);
     size_t o_thr = carve(qc * 8), o_sord = carve(qc * pl.sstride * 8), o_qn = carve(qc * 4);
@@ -672,7 +672,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     pl.rc_pos = (uint32_t *)(b + o_rcp); pl.rc_dist = (float *)(b + o_rcd); pl.rc_max = (float *)(b + o_rcm);
     pl.rflag = (uint32_t *)(b + o_rfl); pl.rc_cnt = (uint32_t *)(b + o_rcc);
     pl.order = (uint32_t *)(b + o_ord);
-    pl.pair_info = (uint32_t *)(b + o_pi); pl.pair_parent = (uint32_t *)(b + o_pp); pl.pair_sorted = (uint32_t *)(b + o_ps);
+    pl.pair_info = (uint32_t *)(b + o_pi); pl.pair_parent = (uint32_t *)(b + o_pp); pl.pair_sorted = (uint32_t *)(b + o_ps); pl.pair_slot = (uint32_t *)(b + o_pl);
     pl.small_flag = (uint32_t *)(b + o_sf);
     pl.grp_cnt = (uint32_t *)(b + o_gc); pl.grp_poff = (uint32_t *)(b + o_gp); pl.grp_ioff = (uint32_t *)(b + o_gi);
     pl.grp_fill = (uint32_t *)(b + o_gf);
@@ -823,8 +823,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             grouped_filter = !stats && g.n && bound <= 512 * 32 && !no_filter;
             hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, pl.grp_cnt, wprev, pl.grp_poff, pl.grp_ioff, pl.grp_fill,
                                reinterpret_cast<uint4 *>(pl.grp_item), grouped_filter ? ix->lvl[l - 1].child_rows : nullptr);
-            hipLaunchKernelGGL(pair_fill_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pl.pair_info, pl.pair_parent, total,
-                               pl.grp_poff, pl.grp_fill, pl.pair_sorted);
+            hipLaunchKernelGGL(pair_fill_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pl.pair_info, pl.pair_parent, pl.pair_slot,
+                               total, pl.grp_poff, pl.pair_sorted);
             const uint32_t items = (total + kGroupPairs - 1) / kGroupPairs + std::min(wprev, total);
             if (grouped_filter) {
                 // approximate distances of all pairs on the matrix cores, then the same prefilter / exact
@@ -863,7 +863,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             const uint64_t expect_next = std::min<uint64_t>(fb, pl.probes) * ix->level_width[l + 1] / std::max<uint32_t>(ix->level_width[l], 1);
             if ((stats || bound_next > std::max<uint32_t>(pl.probes, 100)) && (expect_next >= 256 || (flags & CUDDLE_SEARCH_ROUTE_GROUPED))) {
                 group_next = true;
-                po.info = pl.pair_info; po.parent = pl.pair_parent; po.cnt = pl.grp_cnt; po.small = pl.small_flag;
+                po.info = pl.pair_info; po.parent = pl.pair_parent; po.slot = pl.pair_slot; po.cnt = pl.grp_cnt; po.small = pl.small_flag;
                 po.pstride = pl.probes;
                 po.min_n = stats ? 0u : std::max<uint32_t>(pl.probes, 100);
                 HIP_TRY(hipMemsetAsync(pl.grp_cnt, 0, ((size_t)ix->level_width[l] + 1) * 4, s));

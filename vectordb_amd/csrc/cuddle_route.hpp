@@ -77,6 +77,7 @@ __device__ __forceinline__ uint32_t block_radix_select(uint32_t n, uint32_t want
 struct PairOut {
     uint32_t *info = nullptr;
     uint32_t *parent = nullptr;
+    uint32_t *slot = nullptr; // the pair's place among its parent's pairs (the value cnt had when it was counted)
     uint32_t *cnt = nullptr;
     uint32_t *small = nullptr;
     uint32_t pstride = 0;
@@ -186,14 +187,15 @@ __device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t 
         const uint32_t nchild = cnt_child[nsel];
         const bool grouped = nf && nchild > po.min_n && nchild <= fstride;
         for (uint32_t i = tid; i < po.pstride; i += blockDim.x) {
-            uint32_t info = 0xFFFFFFFFu, par = 0;
+            uint32_t info = 0xFFFFFFFFu, par = 0, slot = 0;
             if (grouped && i < nsel && cnt_child[i + 1] > cnt_child[i]) {
                 par = ix.level_pos[sel_node[i]];
                 info = (q << kPairOffBits) | cnt_child[i];
-                atomicAdd(&po.cnt[par], 1u);
+                slot = atomicAdd(&po.cnt[par], 1u);
             }
             po.info[(uint64_t)q * po.pstride + i] = info;
             po.parent[(uint64_t)q * po.pstride + i] = par;
+            po.slot[(uint64_t)q * po.pstride + i] = slot;
         }
         if (tid == 0) po.small[q] = grouped ? 0u : 1u;
     }
@@ -497,14 +499,13 @@ pair_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *poff, uint32_t *ioff
 }
 
 // Scatter the pairs into parent order (order inside a group is immaterial).
-__global__ void pair_fill_kernel(const uint32_t *info, const uint32_t *parent, uint32_t total, const uint32_t *poff,
-                                 uint32_t *fill, uint32_t *sorted) {
+__global__ void pair_fill_kernel(const uint32_t *info, const uint32_t *parent, const uint32_t *slot, uint32_t total,
+                                 const uint32_t *poff, uint32_t *sorted) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const uint32_t v = info[i];
     if (v == 0xFFFFFFFFu) return;
-    const uint32_t p = parent[i];
-    sorted[poff[p] + atomicAdd(&fill[p], 1u)] = v;
+    sorted[poff[parent[i]] + slot[i]] = v;
 }
 
 // One block per work item = (parent, up to kGroupPairs of its pairs); blocks past the last item
