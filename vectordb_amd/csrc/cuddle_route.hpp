@@ -456,10 +456,9 @@ route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride,
 // Exclusive prefix sums over the per-parent pair counts: poff = pairs, ioff = work items (blocks of
 // up to kGroupPairs pairs of one parent); items[item] = (parent, first pair, pairs, 0), or, with
 // child_rows (per parent: table row of its first child, number of children) given, (first pair,
-// pairs, row, children) for route_gemm_grouped_kernel; also clears the fill counters. One block of 1024 threads; the per-parent arrays hold n + 1 entries.
+// pairs, row, children) for route_gemm_grouped_kernel. One block of 1024 threads; the per-parent arrays hold n + 1 entries.
 __global__ void __launch_bounds__(1024)
-pair_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *poff, uint32_t *ioff, uint32_t *fill, uint4 *items,
-                 const uint2 *child_rows) {
+pair_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *poff, uint32_t *ioff, uint4 *items, const uint2 *child_rows) {
     __shared__ uint32_t sp[1024], si[1024];
     const uint32_t tid = threadIdx.x, per = (n + 1023) / 1024;
     const uint32_t b = min(tid * per, n), e = min(b + per, n);
@@ -483,7 +482,6 @@ pair_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *poff, uint32_t *ioff
         const uint32_t c = cnt[i], ni = (c + kGroupPairs - 1) / kGroupPairs;
         poff[i] = rp;
         ioff[i] = ri;
-        fill[i] = 0;
         const uint2 cr = child_rows ? child_rows[i] : make_uint2(0u, 0u);
         for (uint32_t t = 0; t < ni; ++t) {
             const uint32_t first = rp + t * kGroupPairs, np = min((uint32_t)kGroupPairs, c - t * kGroupPairs);
