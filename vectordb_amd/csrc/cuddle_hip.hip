@@ -891,8 +891,14 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                                pl.rflag, &ix->d_stats->fallbacks, po);
             only = pl.rflag; // queries whose selection could not be proven exact fall through to the exact kernels
         }
-        if (!keep_all) // after a filter path only the (rare) flagged queries do work here: one block per query; after the exact grouped path the small frontiers
-            hipLaunchKernelGGL(route_dist_kernel, dim3((use_gemm || grouped_filter) ? 1 : grouped ? 4 : std::min<uint32_t>((bound + 63) / 64, 64), nq), dim3(256), v.dim * sizeof(float), s, v, dq,
+        // blocks per query of the exact distance kernel (they stride over the frontier): after a filter path only the
+        // (rare) flagged queries do work there; after the exact grouped path only the small frontiers; a per-query
+        // level that was not worth grouping has, typically, frontiers of fewer than 256 nodes whatever the bound says
+        // (and blocks that find nothing to do still cost their dispatch); a shared level's width is known
+        const uint32_t dist_gx = (use_gemm || grouped_filter) ? 1 : grouped ? 4
+                                 : std::min<uint32_t>((bound + 63) / 64, (shared || (flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY)) ? 64 : 8);
+        if (!keep_all)
+            hipLaunchKernelGGL(route_dist_kernel, dim3(dist_gx, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                pl.frontier[cur], pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, only, pl.qnorm);
         const uint32_t *sel_only = (grouped && !grouped_filter) ? nullptr : only; // after the exact grouped path every query still selects here
 #define CUDDLE_SELECT_REG(T, K)                                                                                              \
