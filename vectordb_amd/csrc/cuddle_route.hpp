@@ -456,43 +456,118 @@ route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride,
 // Exclusive prefix sums over the per-parent pair counts: poff = pairs, ioff = work items (blocks of
 // up to kGroupPairs pairs of one parent); items[item] = (parent, first pair, pairs, 0), or, with
 // child_rows (per parent: table row of its first child, number of children) given, (first pair,
-// pairs, row, children) for route_gemm_grouped_kernel. One block of 1024 threads; the per-parent arrays hold n + 1 entries.
-__global__ void __launch_bounds__(1024)
-pair_scan_kernel(const uint32_t *cnt, uint32_t n, uint32_t *poff, uint32_t *ioff, uint4 *items, const uint2 *child_rows) {
-    __shared__ uint32_t sp[1024], si[1024];
-    const uint32_t tid = threadIdx.x, per = (n + 1023) / 1024;
-    const uint32_t b = min(tid * per, n), e = min(b + per, n);
-    uint32_t ap = 0, ai = 0;
-    for (uint32_t i = b; i < e; ++i) {
-        ap += cnt[i];
-        ai += (cnt[i] + kGroupPairs - 1) / kGroupPairs;
+// pairs, row, children) for route_gemm_grouped_kernel. The per-parent arrays hold n + 1 entries.
+// Three launches, so that a level of millions of parents is scanned by as many blocks as it needs:
+//   pair_block_sums_kernel  grid nb = ceil(n / 1024), block 256: bsum[b], bsum[nb + b] = pairs, items of block b's parents
+//   pair_block_scan_kernel  one block of 1024: bsum -> exclusive offsets in place; totals to poff[n], ioff[n]
+//   pair_scan_kernel        grid nb, block 256: offsets of each parent, and its items
+constexpr uint32_t kPairScanChunk = 1024; // parents per block: 4 per thread
+
+__device__ __forceinline__ uint32_t pair_items_of(uint32_t c) { return (c + kGroupPairs - 1) / kGroupPairs; }
+
+// Block-wide exclusive scan of (a, b) over 256 threads; returns the block totals in (ta, tb).
+__device__ __forceinline__ void block256_exclusive_scan2(uint32_t &a, uint32_t &b, uint32_t &ta, uint32_t &tb, uint32_t *lds8) {
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t ia = wave_inclusive_sum(a), ib = wave_inclusive_sum(b);
+    if (lane == 63) {
+        lds8[w] = ia;
+        lds8[4 + w] = ib;
     }
-    sp[tid] = ap;
-    si[tid] = ai;
     __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        const uint32_t vp = tid >= o ? sp[tid - o] : 0, vi = tid >= o ? si[tid - o] : 0;
+    uint32_t oa = 0, ob = 0;
+    ta = tb = 0;
+    for (uint32_t v = 0; v < 4; ++v) {
+        if (v < w) {
+            oa += lds8[v];
+            ob += lds8[4 + v];
+        }
+        ta += lds8[v];
+        tb += lds8[4 + v];
+    }
+    a = oa + ia - a;
+    b = ob + ib - b;
+}
+
+__global__ void __launch_bounds__(256)
+pair_block_sums_kernel(const uint32_t *cnt, uint32_t n, uint32_t *bsum, uint32_t nb) {
+    __shared__ uint32_t lds8[8];
+    const uint32_t base = blockIdx.x * kPairScanChunk + threadIdx.x * 4;
+    uint32_t ap = 0, ai = 0;
+    for (uint32_t k = 0; k < 4; ++k)
+        if (base + k < n) {
+            const uint32_t c = cnt[base + k];
+            ap += c;
+            ai += pair_items_of(c);
+        }
+    uint32_t tp, ti;
+    block256_exclusive_scan2(ap, ai, tp, ti, lds8);
+    if (threadIdx.x == 0) {
+        bsum[blockIdx.x] = tp;
+        bsum[nb + blockIdx.x] = ti;
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+pair_block_scan_kernel(uint32_t *bsum, uint32_t nb, uint32_t n, uint32_t *poff, uint32_t *ioff) {
+    __shared__ uint32_t sp[1024], si[1024];
+    const uint32_t tid = threadIdx.x;
+    uint32_t carry_p = 0, carry_i = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += 1024) { // block-uniform trip count
+        const uint32_t b = b0 + tid;
+        const uint32_t vp = b < nb ? bsum[b] : 0, vi = b < nb ? bsum[nb + b] : 0;
+        sp[tid] = vp;
+        si[tid] = vi;
         __syncthreads();
-        sp[tid] += vp;
-        si[tid] += vi;
+        for (uint32_t o = 1; o < 1024; o <<= 1) {
+            const uint32_t xp = tid >= o ? sp[tid - o] : 0, xi = tid >= o ? si[tid - o] : 0;
+            __syncthreads();
+            sp[tid] += xp;
+            si[tid] += xi;
+            __syncthreads();
+        }
+        if (b < nb) {
+            bsum[b] = carry_p + sp[tid] - vp;
+            bsum[nb + b] = carry_i + si[tid] - vi;
+        }
+        carry_p += sp[1023];
+        carry_i += si[1023];
         __syncthreads();
     }
-    uint32_t rp = sp[tid] - ap, ri = si[tid] - ai;
-    for (uint32_t i = b; i < e; ++i) {
-        const uint32_t c = cnt[i], ni = (c + kGroupPairs - 1) / kGroupPairs;
+    if (tid == 0) {
+        poff[n] = carry_p;
+        ioff[n] = carry_i;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+pair_scan_kernel(const uint32_t *cnt, uint32_t n, const uint32_t *bsum, uint32_t nb, uint32_t *poff, uint32_t *ioff,
+                 uint4 *items, const uint2 *child_rows) {
+    __shared__ uint32_t lds8[8];
+    const uint32_t base = blockIdx.x * kPairScanChunk + threadIdx.x * 4;
+    uint32_t c4[4], ap = 0, ai = 0;
+    for (uint32_t k = 0; k < 4; ++k) {
+        c4[k] = base + k < n ? cnt[base + k] : 0;
+        ap += c4[k];
+        ai += pair_items_of(c4[k]);
+    }
+    uint32_t tp, ti;
+    block256_exclusive_scan2(ap, ai, tp, ti, lds8);
+    uint32_t rp = bsum[blockIdx.x] + ap, ri = bsum[nb + blockIdx.x] + ai;
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t i = base + k;
+        if (i >= n) break;
+        const uint32_t c = c4[k], ni = pair_items_of(c);
         poff[i] = rp;
         ioff[i] = ri;
-        const uint2 cr = child_rows ? child_rows[i] : make_uint2(0u, 0u);
-        for (uint32_t t = 0; t < ni; ++t) {
-            const uint32_t first = rp + t * kGroupPairs, np = min((uint32_t)kGroupPairs, c - t * kGroupPairs);
-            items[ri + t] = child_rows ? make_uint4(first, np, cr.x, cr.y) : make_uint4(i, first, np, 0u);
+        if (ni) {
+            const uint2 cr = child_rows ? child_rows[i] : make_uint2(0u, 0u);
+            for (uint32_t t = 0; t < ni; ++t) {
+                const uint32_t first = rp + t * kGroupPairs, np = min((uint32_t)kGroupPairs, c - t * kGroupPairs);
+                items[ri + t] = child_rows ? make_uint4(first, np, cr.x, cr.y) : make_uint4(i, first, np, 0u);
+            }
         }
         rp += c;
         ri += ni;
-    }
-    if (tid == 1023) {
-        poff[n] = sp[1023];
-        ioff[n] = si[1023];
     }
 }
 
