@@ -719,7 +719,7 @@ static cuddle_status launch_quantize(cuddle_index *ix, const Plan &pl, const flo
     const IndexDev &v = ix->dev;
     if (v.code_kind == CUDDLE_CODE_BINARY) {
         uint64_t total = (uint64_t)nq * v.words;
-        hipLaunchKernelGGL(binary_quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dq, (uint64_t)nq,
+        hipLaunchKernelGGL(binary_quantize_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, dq, (uint64_t)nq,
                            v.dim, v.words, ix->threshold, pl.qcodes);
     } else {
         float *rq = reinterpret_cast<float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
@@ -1195,7 +1195,7 @@ extern "C" cuddle_status cuddle_binary_quantize(const float *vectors, uint64_t n
     ST_TRY(dv.alloc((size_t)n * dim * 4)); ST_TRY(dc.alloc((size_t)n * W * 8));
     HIP_TRY(hipMemcpy(dv.p, vectors, (size_t)n * dim * 4, hipMemcpyHostToDevice));
     uint64_t total = n * W;
-    hipLaunchKernelGGL(binary_quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, (const float *)dv.p, n,
+    hipLaunchKernelGGL(binary_quantize_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, 0, (const float *)dv.p, n,
                        dim, W, threshold, (uint64_t *)dc.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(codes, dc.p, (size_t)n * W * 8, hipMemcpyDeviceToHost));

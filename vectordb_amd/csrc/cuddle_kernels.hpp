@@ -646,19 +646,17 @@ __global__ void distance_pairs_kernel(const float *a, const float *b, uint64_t n
     if (act && sub == 0) out[g] = d;
 }
 
-// BinaryQuantizer::quantize (binary.rs:144-159): one thread per (vector, word).
-__global__ void binary_quantize_kernel(const float *v, uint64_t n, uint32_t dim, uint32_t words, float thr,
-                                       uint64_t *codes) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// BinaryQuantizer::quantize (binary.rs:144-159): one wave per (vector, word); lane i tests value
+// 64 w + i (strict >), the wave's ballot is the word (bit i = lane i, pad bits 0).
+// grid = ceil(n * words / 4), block 256.
+__global__ void __launch_bounds__(256)
+binary_quantize_kernel(const float *v, uint64_t n, uint32_t dim, uint32_t words, float thr, uint64_t *codes) {
+    const uint64_t t = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t >= n * words) return;
-    uint64_t r = t / words;
-    uint32_t w = (uint32_t)(t % words);
-    const float *x = v + r * dim;
-    uint64_t bits = 0;
-    uint32_t lim = min(64u, dim - w * 64u);
-    for (uint32_t i = 0; i < lim; ++i)
-        if (x[w * 64 + i] > thr) bits |= 1ull << i;
-    codes[t] = bits;
+    const uint32_t lane = threadIdx.x & 63, w = (uint32_t)(t % words), i = w * 64 + lane;
+    const bool bit = i < dim && v[(t / words) * dim + i] > thr;
+    const uint64_t bits = __ballot(bit);
+    if (lane == 0) codes[t] = bits;
 }
 
 // hamming_distance (binary.rs:42-54) for n pairs.
