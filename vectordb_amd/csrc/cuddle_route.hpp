@@ -199,19 +199,23 @@ __device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t 
         }
         if (tid == 0) po.small[q] = grouped ? 0u : 1u;
     }
-    // one wave per chosen node: leaves are appended, children copied with coalesced stores
-    const uint32_t nw = blockDim.x >> 6, w = tid >> 6, lane = tid & 63;
-    for (uint32_t i = w; i < nsel; i += nw) {
-        const uint32_t cb = sel_cb[i], cc = cnt_child[i + 1] - cnt_child[i];
-        if (cc == 0) {
-            if (lane == 0) {
-                const uint32_t slot = lbase + cnt_leaf[i];
-                if (slot < lstride) lv[slot] = sel_node[i];
+    // leaves are appended by the thread of their selection slot; the children are copied one output
+    // position per thread (the owning node found by bisection of the prefix sums in LDS), so that a
+    // selection of many small families costs as little as one of a few large ones
+    for (uint32_t i = tid; i < nsel; i += blockDim.x)
+        if (cnt_child[i + 1] == cnt_child[i]) {
+            const uint32_t slot = lbase + cnt_leaf[i];
+            if (slot < lstride) lv[slot] = sel_node[i];
+        }
+    if (nf) {
+        const uint32_t total = min(cnt_child[nsel], fstride);
+        for (uint32_t o = tid; o < total; o += blockDim.x) {
+            uint32_t lo = 0, hi = nsel; // cnt_child[lo] <= o < cnt_child[hi]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (cnt_child[mid] <= o) lo = mid; else hi = mid;
             }
-        } else if (nf) {
-            const uint32_t ob = cnt_child[i];
-            for (uint32_t c = lane; c < cc; c += 64)
-                if (ob + c < fstride) nf[ob + c] = ix.children[cb + c];
+            nf[o] = ix.children[sel_cb[lo] + (o - cnt_child[lo])];
         }
     }
 }
