@@ -1,44 +1,46 @@
 #!/usr/bin/env python3
 """Benchmark of the batched two-phase ANN query path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (route -> Hamming scan + select -> fp32 rerank -> top-k)
-over one batch of queries already resident in HBM. Default workload: "GIST1M (1M x 960-d f32,
-L2, k=10) two-phase search on one MI355X" — GIST1M itself is not in the
-container and cannot be fetched, so the data is a seeded GIST1M-shaped synthetic mixture, labelled
-as such. probes = 200 and the rerank sweep {5,10,25,50,100} are the reference's GIST settings
+N > 1: one rank per GPU. Either the launcher provides the ranks (torch.distributed.run: RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, when RANK is not set, this script
+starts the N rank processes itself (before anything touches a GPU) and relays rank 0's line.
+
+One "step" = one pass of the hot path (route -> code scan + select -> fp32 rerank -> top-k) over
+one batch of queries already resident in HBM; the timed loop rotates through 8 different query
+batches so that no step replays the one before it. Default workload: "GIST1M (1M x 960-d f32, L2,
+k=10) two-phase search on one MI355X" — GIST1M itself is not in the container and cannot be
+fetched, so the data is a seeded GIST1M-shaped synthetic mixture, labelled as such. probes = 200
+and the rerank sweep {5,10,25,50,100} are the reference's GIST settings
 (/root/reference/benches/gist_benchmark.rs:177-183); the timed operating point is the cheapest
 sweep point whose recall@10 against brute-force ground truth is >= 0.95.
 
 Rank 0 prints ONE JSON line: metric/value/unit (whole-job queries per second), the timing
-contract fields, recall, batch-latency percentiles, `roofline` (dominant kernel = the Hamming
-scan: algorithmic code bytes per launch / mean launch time from HIP events, against the 8 TB/s
-HBM peak) and `cpu_baseline` (the CPU oracle timed on this host).
+contract fields, recall, batch-latency percentiles, `roofline` (dominant kernel = the code scan:
+algorithmic code bytes per launch / mean launch time from HIP events on the launch stream, against
+the 8 TB/s HBM peak), `roofline_hbm_resident` (the same kernel on a 10M x 960-d index whose 1.2 GB
+of codes cannot sit in the 256 MiB Infinity Cache; default workload at N = 1 only) and
+`cpu_baseline` (the CPU oracle timed on this host).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from vectordb_amd import _ffi  # noqa: E402
-from vectordb_amd.builder import build_index  # noqa: E402
-from vectordb_amd.datasets import brute_force_topk, recall_at_k, synthetic_mixture  # noqa: E402
-from vectordb_amd.flat_index import FlatIndex  # noqa: E402
-from vectordb_amd.index import DeviceIndex  # noqa: E402
-from vectordb_amd.sharded import ExactShardedSearcher, ShardedSearcher  # noqa: E402
-
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+N_BATCHES = 8           # distinct query batches the timed loop rotates through
 
 CONFIGS = {
     # name: data shape + the reference's search settings for that dataset
@@ -52,15 +54,21 @@ CONFIGS = {
                    latent_dim=24,
                    label="SIFT1M-shaped synthetic (1M x 128 integer-valued f32: two-level Gaussian mixture of intrinsic "
                          "dimension 24 embedded linearly in 128-d)"),
-    # one GPU's share of the leaf-sharded 100M / 1B x 128-d configs (index by construction, built on the device)
+    # the GIST shape past the Infinity Cache: 10M x 960 (1.2 GB of codes, 38 GB of fp32 rows), tree by construction
+    "gist10m": dict(n=46 ** 3 * 103, dim=960, n_queries=1000, k=10, metric="l2", style="gauss", probes=200,
+                    rerank_sweep=[5, 10, 25, 50, 100], code_kind="binary", tree=(46, 3, 103), gt_queries=500,
+                    label="synthetic 10M x 960 f32 hierarchical Gaussian (1.2 GB of binary codes + 38 GB of fp32 rows in HBM), "
+                          "tree by construction (46-way x 3 levels, 103-vector leaves)"),
+    # one GPU's share of the leaf-sharded 100M / 1B x 128-d configs (index by construction, built on the device).
+    # With N ranks the index is N such shards (N x 12.5M / N x 125M vectors): every rank generates its own leaves.
     "shard12m": dict(n=12_500_000, dim=128, n_queries=4096, k=10, metric="l2", style="sift", probes=100,
                      rerank_sweep=[5, 10, 25, 50, 100, 200], code_kind="binary", tree=(50, 3, 100), gt_queries=1000,
-                     label="one of 8 leaf shards of a synthetic 100M x 128 index: 12.5M x 128 integer-valued f32, "
+                     label="12.5M x 128 integer-valued f32 per GPU (one of 8 leaf shards of a synthetic 100M x 128 index), "
                            "hierarchical Gaussian, tree by construction (50-way x 3 levels, 100-vector leaves)"),
     "shard125m": dict(n=125_000_000, dim=128, n_queries=4096, k=10, metric="l2", style="sift", probes=100,
                       rerank_sweep=[5, 10, 25, 50, 100, 200], code_kind="binary", tree=(100, 3, 125), gt_queries=1000,
-                      label="one of 8 leaf shards of a synthetic 1B x 128 index: 125M x 128 integer-valued f32 "
-                            "(2 GB codes + 64 GB fp32 in HBM), tree by construction (100-way x 3 levels, 125-vector leaves)"),
+                      label="125M x 128 integer-valued f32 per GPU (one of 8 leaf shards of a synthetic 1B x 128 index: "
+                            "2 GB codes + 64 GB fp32 in HBM), tree by construction (100-way x 3 levels, 125-vector leaves)"),
     # config 3: RaBitQ codes, cosine, k = 100 (tree by construction: 46-way x 3 levels, 103-vector leaves = 10.03M vectors)
     "rabitq10m": dict(n=46 ** 3 * 103, dim=768, n_queries=4096, k=100, metric="cosine", style="gauss", probes=100,
                       rerank_sweep=[10, 20, 40], code_kind="rabitq", tree=(46, 3, 103), gt_queries=500,
@@ -69,6 +77,9 @@ CONFIGS = {
     "tiny": dict(n=20_000, dim=64, n_queries=256, k=10, metric="l2", style="gist", probes=8,
                  rerank_sweep=[5, 10, 25, 50, 100], branching=16, leaf=50, code_kind="binary", latent_dim=0,
                  label="tiny synthetic (20k x 64)"),
+    "tinytree": dict(n=8 ** 3 * 20, dim=32, n_queries=128, k=10, metric="l2", style="sift", probes=16,
+                     rerank_sweep=[5, 10, 25, 50], code_kind="binary", tree=(8, 3, 20), gt_queries=128,
+                     label="tiny tree by construction (8-way x 3 levels, 20-vector leaves per GPU)"),
 }
 
 
@@ -83,8 +94,47 @@ def trace(msg):
         print(f"[bench rank {os.environ.get('RANK', '0')} {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def spawn_ranks(n: int) -> int:
+    """Start the N rank processes of this same command line (fresh interpreters: this parent never touches a
+    GPU), wait for them, relay rank 0's output. A rank that fails ends the others and the job."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr, flush=True)
+                for o in pending:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    out0.seek(0)
+    sys.stdout.write(out0.read())
+    sys.stdout.flush()
+    return rc
+
+
 def broadcast_flat(fi, src_rank, device):
-    """Rank `src_rank` sends its FlatIndex to every rank (RCCL broadcast of each array)."""
+    """Rank `src_rank` sends its FlatIndex to every rank (broadcast of each array)."""
+    import torch
+    import torch.distributed as dist
+
+    from vectordb_amd.flat_index import FlatIndex
+
     rank = dist.get_rank()
     names = ["centroids", "child_offsets", "children", "roots", "vec_offsets", "ids", "vectors", "codes"]
     meta = [None]
@@ -93,18 +143,33 @@ def broadcast_flat(fi, src_rank, device):
                        arrays={n: (getattr(fi, n).shape, str(getattr(fi, n).dtype)) for n in names})
     dist.broadcast_object_list(meta, src=src_rank)
     m = meta[0]
+    via_host = dist.get_backend() == "gloo"
     arrays = {}
     for n in names:
         shape, dt = m["arrays"][n]
         nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
+        where = "cpu" if via_host else device
         if rank == src_rank:
-            t = torch.from_numpy(getattr(fi, n).reshape(-1).view(np.uint8)).to(device)
+            t = torch.from_numpy(getattr(fi, n).reshape(-1).view(np.uint8)).to(where)
         else:
-            t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            t = torch.empty(nbytes, dtype=torch.uint8, device=where)
         dist.broadcast(t, src=src_rank)
         arrays[n] = t.cpu().numpy().view(np.dtype(dt)).reshape(shape)
         del t
     return FlatIndex(dim=m["dim"], metric=m["metric"], code_kind=m["code_kind"], threshold=m["threshold"], **arrays)
+
+
+def host_cpu_info():
+    """What the CPU baseline ran on: CPUs of the machine, CPUs this process may use, threads used."""
+    nproc = os.cpu_count() or 1
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = nproc
+    # the GPU box gives a one-GPU job a share of 16 CPUs of the machine (OMP_NUM_THREADS is set to it)
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    threads = max(1, min(allowed, share if share > 0 else 16))
+    return nproc, allowed, threads
 
 
 def cpu_baseline(fi, queries_np, k, probes, rf, budget_s=12.0):
@@ -112,7 +177,7 @@ def cpu_baseline(fi, queries_np, k, probes, rf, budget_s=12.0):
     on this host's cores over a bounded sample of the same queries."""
     from oracle import oracle as orc  # test infrastructure; used here only as the timed CPU baseline
 
-    threads = max(1, min(16, os.cpu_count() or 1))
+    nproc, allowed, threads = host_cpu_info()
     oi = orc.OracleIndex(fi)
     n = min(32, queries_np.shape[0])
     t0 = time.perf_counter()
@@ -120,7 +185,7 @@ def cpu_baseline(fi, queries_np, k, probes, rf, budget_s=12.0):
     dt = time.perf_counter() - t0
     per_q = dt / n
     sample = int(min(queries_np.shape[0], max(n, budget_s / max(per_q, 1e-9))))
-    # at least ~1 s of wall time (about 16 core-seconds): repeat the sample if it is the whole query set
+    # at least ~1 s of wall time: repeat the sample if it is the whole query set
     passes, dt = 0, 0.0
     while passes == 0 or (dt < 1.0 and passes < 64):
         t0 = time.perf_counter()
@@ -133,14 +198,326 @@ def cpu_baseline(fi, queries_np, k, probes, rf, budget_s=12.0):
     _, ids_seq, _, _ = oi.search_sequential(queries_np[:n_seq], k, probes, rf, 0, threads)
     dt_seq = time.perf_counter() - t0
     return dict(value=sample * passes / dt, unit="queries/s", cores=threads, kind="port",
-                sample=f"{sample} of the {queries_np.shape[0]} benchmark queries x {passes} passes, same index and parameters, "
-                       f"{dt:.1f} s wall, oracle/cuddle_oracle.c with OpenMP (one query per thread)",
+                host_cpus=nproc, cpus_available_to_this_process=allowed,
+                cores_note=f"{threads} OpenMP threads = this job's CPU share of the host ({nproc} CPUs in the machine, "
+                           f"{allowed} in this process's affinity mask)",
+                sample=f"{sample} of the {queries_np.shape[0]} queries of the first batch x {passes} passes, same index and "
+                       f"parameters, {dt:.1f} s wall, oracle/cuddle_oracle.c with OpenMP (one query per thread)",
                 reference_shaped=dict(value=n_seq / dt_seq, unit="queries/s", cores=threads,
                                       mean_latency_ms=dt_seq / n_seq * 1e3,
                                       identical_to_batch_parallel=bool(np.array_equal(ids_seq, ids[:n_seq])),
                                       sample=f"{n_seq} queries issued one after another, each search() spreading its routing "
                                              f"(> 100 nodes), code scan and rerank loops over the {threads} threads, as the "
                                              f"reference's rayon calls do")), ids, sample
+
+
+def merged_ground_truth(local_rows, local_dist, local_ids, k, world):
+    """Global top-k ids from every rank's local brute-force top-k (rows of its shard -> ids)."""
+    import torch
+    import torch.distributed as dist
+
+    ids = local_ids[local_rows.clamp_min(0)]
+    ids = torch.where(local_rows < 0, torch.full_like(ids, -1), ids)
+    if world == 1:
+        return ids.cpu().numpy()
+    all_i = torch.empty((world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+    all_d = torch.empty((world,) + tuple(local_dist.shape), dtype=local_dist.dtype, device=ids.device)
+    if dist.get_backend() == "gloo":
+        hi, hd = all_i.cpu(), all_d.cpu()
+        dist.all_gather(list(hi.unbind(0)), ids.cpu())
+        dist.all_gather(list(hd.unbind(0)), local_dist.cpu())
+        all_i, all_d = hi.to(ids.device), hd.to(ids.device)
+    else:
+        dist.all_gather_into_tensor(all_i.view(-1, ids.shape[1]), ids.contiguous())
+        dist.all_gather_into_tensor(all_d.view(-1, ids.shape[1]), local_dist.contiguous())
+    nq = ids.shape[0]
+    d = all_d.permute(1, 0, 2).reshape(nq, -1)
+    i = all_i.permute(1, 0, 2).reshape(nq, -1)
+    _, sel = torch.topk(d, k, dim=1, largest=False)
+    return torch.gather(i, 1, sel).cpu().numpy()
+
+
+def run_config(name, args, rank, world, local_rank, device, backend, steps, warmup, want_cpu, want_filter):
+    """Builds the configuration's index, finds the operating point, times `steps` steps and returns rank 0's
+    result dictionary (None on the other ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    from vectordb_amd import _ffi
+    from vectordb_amd.builder import build_index, metric_id
+    from vectordb_amd.datasets import brute_force_topk, recall_at_k, synthetic_mixture
+    from vectordb_amd.flat_index import FlatIndex, pack_binary_codes
+    from vectordb_amd.index import DeviceIndex
+    from vectordb_amd.sharded import ExactShardedSearcher, ShardedSearcher
+
+    cfg = dict(CONFIGS[name])
+    if args.n and "tree" not in cfg:
+        cfg["n"] = args.n
+    k, probes = cfg["k"], (args.probes or cfg["probes"])
+    nq = cfg["n_queries"]
+    by_construction = "tree" in cfg
+
+    # ---- data + index ----------------------------------------------------------------------------
+    fi = None
+    t_setup = time.perf_counter()
+    dev_index = None
+    if by_construction:
+        # generated and indexed on the device, never copied through the host; with several ranks every rank
+        # generates the leaves it owns (leaf j -> rank j mod N) and the index is N shards of cfg["n"] vectors
+        from vectordb_amd.synthetic import build_tree_index_on_device
+        fanout, levels, leaf_size = cfg["tree"]
+        log(f"generating {cfg['label']}" + (f" x {world} ranks" if world > 1 else ""))
+        dti, all_q = build_tree_index_on_device(cfg["dim"], fanout, levels, leaf_size, device, seed=0xC0DD1E,
+                                                n_queries=nq * N_BATCHES, metric=metric_id(cfg["metric"]),
+                                                style=cfg.get("style", "sift"),
+                                                code_kind=_ffi.CODE_RABITQ if cfg["code_kind"] == "rabitq" else _ffi.CODE_BINARY,
+                                                rank=rank, world=world)
+        log("ground truth (GPU brute force) on a query sample")
+        gq = min(cfg.get("gt_queries", nq), nq)
+        rows, dd = brute_force_topk(dti.vectors, all_q[:gq], k, cfg["metric"], chunk=1 << 20, return_dist=True)
+        gt = merged_ground_truth(rows, dd, dti.ids, k, world)
+        del rows, dd
+        dev_index = dti.create(local_rank)
+        log(f"index: {dti.centroids.shape[0]} nodes, {dti.n_vectors} vectors on this rank, threshold {dti.threshold:.6g}")
+        n_total = dti.n_vectors * world
+    else:
+        gt = None
+        if rank == 0:
+            log(f"generating {cfg['label']}: n={cfg['n']} dim={cfg['dim']}")
+            base, all_q = synthetic_mixture(cfg["n"], cfg["dim"], seed=0xC0DD1E, device=device, style=cfg["style"],
+                                            n_queries=nq * N_BATCHES, latent_dim=cfg["latent_dim"])
+            log("ground truth (GPU brute force)")
+            gt = brute_force_topk(base, all_q[:nq], k, cfg["metric"]).cpu().numpy()
+            log("building index (GPU k-means tree)")
+            # binary threshold = exact mean: the reference's single-precision running sum saturates long
+            # before 10^9 values (it would give 0.017 instead of ~0.4 here and set every code bit)
+            fi = build_index(base, cfg["branching"], cfg["leaf"], cfg["metric"], 20, seed=1, code_kind=cfg["code_kind"],
+                             threshold=args.threshold if args.threshold != "reference" else None)
+            ls = fi.leaf_sizes()
+            log(f"index: {fi.n_nodes} nodes, {len(ls)} leaves (min {ls.min()}, mean {ls.mean():.1f}, max {ls.max()}), "
+                f"{fi.n_levels()} levels, threshold {fi.threshold:.6g}")
+            del base
+            torch.cuda.empty_cache()
+        else:
+            all_q = torch.empty((nq * N_BATCHES, cfg["dim"]), dtype=torch.float32, device=device)
+        if world > 1:
+            if backend == "nccl":
+                dist.broadcast(all_q, src=0)
+            else:
+                h = all_q.cpu()
+                dist.broadcast(h, src=0)
+                all_q.copy_(h)
+            fi = broadcast_flat(fi, 0, device)
+        dev_index = DeviceIndex(fi.shard(rank, world), local_rank)
+        n_total = cfg["n"]
+    batches = [all_q[b * nq:(b + 1) * nq].contiguous() for b in range(N_BATCHES)]
+    log(f"setup {time.perf_counter() - t_setup:.1f} s; device bytes {dev_index.device_bytes / 1e9:.2f} GB")
+
+    flags = _ffi.SEARCH_TIME_STAGES
+    out_ids = torch.empty((nq, k), dtype=torch.int64, device=device)
+    out_dist = torch.empty((nq, k), dtype=torch.float32, device=device)
+    out_cnt = torch.empty((nq,), dtype=torch.int32, device=device)
+    rf_box = [cfg["rerank_sweep"][0]]
+    index_box = [dev_index]
+
+    def local_search(q, kk, pp, rr):
+        return index_box[0].search_batch_device(q, kk, pp, rr, flags, out_ids, out_dist, out_cnt)
+
+    class _ShardEngine:  # this rank's shard behind the three-step interface, stage timing on
+        def shard_scan(self, q, kk, pp, rr, leaves=None, leaf_count=None):
+            return dev_index.shard_scan(q, kk, pp, rr, flags, leaves=leaves, leaf_count=leaf_count)
+
+        def route_device(self, q, pp, out=None):
+            return dev_index.route_device(q, pp, flags, out=out)
+
+        leaf_stride = staticmethod(dev_index.leaf_stride)
+        packed_len = staticmethod(dev_index.packed_len)
+        shard_ties = staticmethod(dev_index.shard_ties)
+        shard_finish = staticmethod(dev_index.shard_finish)
+
+    exact = world > 1 and args.sharded == "exact"
+    # CUDDLE_BENCH_SHARD_ROUTING=0: every rank routes the whole batch (A/B against routing a slice each + all-gather)
+    searcher = (ExactShardedSearcher(_ShardEngine(), shard_routing=os.environ.get("CUDDLE_BENCH_SHARD_ROUTING", "1") != "0")
+                if exact else ShardedSearcher(local_search))
+    step_no = [0]
+
+    def step(batch=None):
+        b = step_no[0] % N_BATCHES if batch is None else batch
+        step_no[0] += 1
+        out = searcher.search_batch(batches[b], k, probes, rf_box[0])
+        if world > 1 and backend != "nccl":
+            torch.cuda.synchronize()  # rehearsal backends stage CUDA tensors through the host on their own streams
+        return out
+
+    def recall_of(ids):
+        return recall_at_k(ids.cpu().numpy()[:len(gt)], gt, k)
+
+    # ---- operating point: cheapest sweep point with recall@k >= 0.95 (first batch) ------------------
+    sweep = []
+    chosen = None
+    for rf in ([args.rerank] if args.rerank else cfg["rerank_sweep"]):
+        rf_box[0] = rf
+        ids, _, _ = step(0)
+        torch.cuda.synchronize()
+        if rank == 0:
+            r = recall_of(ids)
+            sweep.append((rf, r))
+            log(f"probes={probes} rerank_factor={rf}: recall@{k} = {r:.4f}")
+        flag = torch.tensor([1 if (rank == 0 and sweep[-1][1] >= 0.95) else 0])
+        if world > 1:
+            if backend == "nccl":
+                flag = flag.to(device)
+            dist.broadcast(flag, src=0)
+        if int(flag.item()):
+            chosen = rf
+            break
+    if chosen is None:
+        chosen = (args.rerank or cfg["rerank_sweep"][-1])
+    rf_box[0] = chosen
+    trace(f"operating point rf={chosen}")
+    dev_index.stage_times()  # drop the sweep's timings
+
+    # ---- timed region ---------------------------------------------------------------------------
+    for _ in range(warmup):
+        step()
+    dev_index.stage_times()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64)
+        if backend == "nccl":
+            te = te.to(device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    stage = dev_index.stage_times()
+    stats = dev_index.last_stats()
+
+    # per-batch latency distribution (separate loop: one sync per batch), at least 200 samples
+    lat = []
+    for _ in range(max(steps, 200)):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    lat.sort()
+    dev_index.stage_times()
+
+    ids, _, _ = step(0)  # every rank: the search is collective
+    torch.cuda.synchronize()
+    if rank != 0:
+        return None
+    recall = recall_of(ids)
+
+    # ---- roofline of the dominant kernel (the code scan + select) --------------------------------
+    rabitq = cfg["code_kind"] == "rabitq"
+    code_bytes = (4 * ((cfg["dim"] + 31) // 32) + 8) if rabitq else 8 * ((cfg["dim"] + 63) // 64)
+    scan_kernel = "scan_select_rabitq_kernel" if rabitq else "scan_select_hamming_kernel"
+    scan_bytes = stats["vectors_scanned"] * code_bytes           # algorithmic bytes of one launch (this rank, last step)
+    rerank_bytes = stats["vectors_reranked"] * 4 * cfg["dim"]
+    n_timed = max(stage["searches"], 1)
+    scan_ms = stage["scan"] / n_timed
+    achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", f"pmc_hbm_traffic_{name}.json")
+    if world == 1 and os.path.exists(pmc_path):  # measured separately under rocprofv3 --pmc (it cannot run inside this process)
+        pmc = json.load(open(pmc_path))
+        traffic = pmc["kernels"].get(scan_kernel, {}).get("traffic_bytes_per_launch")
+        traffic_src = os.path.relpath(pmc_path, ROOT)
+    code_array = dev_index_codes_bytes = (n_total // world) * code_bytes
+    fits_l3 = code_array <= (256 << 20)
+    roofline = dict(bound="hbm", kernel=scan_kernel, achieved=achieved, peak=HBM_PEAK_GBPS,
+                    unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=traffic, traffic_source=traffic_src,
+                    traffic_kind="L2-miss (fabric) bytes per launch from TCC FETCH_SIZE + WRITE_SIZE; FETCH_SIZE also counts "
+                                 "requests served by the 256 MiB Infinity Cache, so this is HBM traffic only for arrays "
+                                 "that cannot sit in that cache",
+                    algorithmic_bytes_per_launch=scan_bytes, avg_launch_ms=scan_ms,
+                    stage_ms_per_step={n: stage[n] / n_timed for n in _ffi.STAGE_NAMES},
+                    rerank_GBps=(rerank_bytes / (stage["rerank"] / n_timed * 1e-3) / 1e9) if stage["rerank"] > 0 else 0.0,
+                    code_array_bytes=code_array, code_array_fits_infinity_cache=fits_l3,
+                    note=("the whole code array fits the 256 MiB Infinity Cache: achieved is on-die cache bandwidth as much as "
+                          "HBM bandwidth (see roofline_hbm_resident for the same kernel on a code array that does not fit); "
+                          if fits_l3 else "the code array is larger than the 256 MiB Infinity Cache: the scan streams from HBM; ") +
+                         f"achieved = algorithmic code bytes per second; the timed loop rotates {N_BATCHES} query batches")
+    del dev_index_codes_bytes
+
+    # routing filter: approximate (matrix-core) distances against the error bound its proof uses
+    route_filter = []
+    if world == 1 and want_filter:
+        q_host = batches[0][:256].cpu().numpy()
+        for level in range(dev_index.levels):
+            try:
+                ratio, err = dev_index.route_filter_error(q_host, probes, level)
+                route_filter.append({"level": level, "max_err_over_bound": ratio, "max_abs_err": err})
+            except _ffi.CuddleError:
+                pass  # narrow level (exact kernels only) or never a whole frontier
+
+    cpu = None
+    if want_cpu and fi is not None:
+        log("CPU baseline (oracle port, OpenMP)")
+        cpu, cpu_ids, sample = cpu_baseline(fi, batches[0].cpu().numpy(), k, probes, chosen)
+        same = bool(np.array_equal(cpu_ids[:sample].astype(np.int64), ids.cpu().numpy()[:sample])) if (world == 1 or exact) else None
+        cpu["gpu_ids_identical_on_sample"] = same
+
+    # the reference's own threshold (binary.rs:122-141: a sequential f32 sum) beside the exact mean, same operating point
+    ref_threshold = None
+    if (world == 1 and fi is not None and cfg["code_kind"] == "binary" and args.threshold == "mean"
+            and not args.no_reference_threshold):
+        thr_ref = float(_ffi.lib().cuddle_binary_threshold(_ffi.ptr(np.ascontiguousarray(fi.vectors)), fi.n_vectors, fi.dim))
+        alt = FlatIndex(dim=fi.dim, metric=fi.metric, code_kind=fi.code_kind, centroids=fi.centroids,
+                        child_offsets=fi.child_offsets, children=fi.children, roots=fi.roots, vec_offsets=fi.vec_offsets,
+                        ids=fi.ids, vectors=fi.vectors, threshold=thr_ref, codes=pack_binary_codes(fi.vectors, thr_ref))
+        index_box[0] = DeviceIndex(alt, local_rank)
+        ids_ref, _, _ = step(0)
+        torch.cuda.synchronize()
+        ref_threshold = dict(threshold=thr_ref, exact_mean=fi.threshold, rerank_factor=chosen,
+                             **{f"recall_at_{k}": recall_of(ids_ref)})
+        index_box[0].close()
+        index_box[0] = dev_index
+
+    total_q = nq * steps
+    out = {
+        "metric": f"batched QPS at recall@{k}>=0.95",
+        "value": total_q / elapsed,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak" if by_construction else "strong",
+        "vs_baseline": None,
+        "dtype": "f32 sign-masked sums (RaBitQ estimator) + f32 rerank" if rabitq else "u64 xor/popcount scan + f32 rerank",
+        "data": "synthetic",
+        "config": {"workload": cfg["label"] + f", {cfg['metric']}, k={k}, {nq}-query batch, probes_per_level={probes}, "
+                               f"rerank_factor={chosen}" + (f", branching {cfg['branching']} / leaf {cfg['leaf']}" if "branching" in cfg else ""),
+                   "name": name, "binary_threshold": args.threshold, "index_vectors": n_total,
+                   "parallelism": (f"leaf-sharded x{world}, {args.sharded} selection" if world > 1 else "single GPU")},
+        f"recall_at_{k}": recall,
+        "recall_sweep": sweep,
+        "reference_threshold": ref_threshold,
+        "p50_batch_ms": lat[len(lat) // 2],
+        "p99_batch_ms": lat[min(len(lat) - 1, len(lat) * 99 // 100)],
+        "latency_samples": len(lat),
+        "candidates_per_query": stats["vectors_scanned"] / nq,
+        "leaves_per_query": stats["leaves_searched"] / nq,
+        "reranked_per_query": stats["vectors_reranked"] / nq,
+        "route_fallbacks_per_batch": stats["route_fallbacks"],
+        "route_filter": route_filter,
+        "max_candidates": stats["max_candidates"],
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    dev_index.close()
+    return out
 
 
 def main():
@@ -152,6 +529,9 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="override the number of base vectors (smoke runs)")
     ap.add_argument("--rerank", type=int, default=0, help="fix rerank_factor instead of sweeping")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-probe", action="store_true",
+                    help="skip the extra measurement of the scan on the 10M x 960 index (default workload, one GPU)")
+    ap.add_argument("--no-reference-threshold", action="store_true")
     ap.add_argument("--threshold", default="mean", choices=["mean", "reference"],
                     help="binary threshold: exact mean, or the reference's saturating f32 running sum")
     ap.add_argument("--probes", type=int, default=0)
@@ -159,6 +539,12 @@ def main():
                     help="N > 1: 'exact' reproduces the single-index result bit for bit (two small all-reduces + one "
                          "all-gather per batch); 'simple' lets every rank rerank its own top candidates (one all-gather)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # this process stays off the GPU; the ranks are fresh interpreters
+
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,238 +562,20 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    cfg = dict(CONFIGS[args.config])
-    if args.n:
-        cfg["n"] = args.n
-    k, probes = cfg["k"], (args.probes or cfg["probes"])
-
-    # ---- data + index (rank 0), then broadcast --------------------------------------------
-    fi = None
-    gt = None
-    t_setup = time.perf_counter()
-    dev_index = None
-    if "tree" in cfg:
-        # large shard: generated and indexed on the device, never copied through the host
-        from vectordb_amd.synthetic import build_tree_index_on_device
-        assert world == 1, "the shard configs measure one GPU's share"
-        fanout, levels, leaf_size = cfg["tree"]
-        log(f"generating {cfg['label']}")
-        from vectordb_amd.builder import metric_id
-        dti, queries = build_tree_index_on_device(cfg["dim"], fanout, levels, leaf_size, device, seed=0xC0DD1E,
-                                                  n_queries=cfg["n_queries"], metric=metric_id(cfg["metric"]),
-                                                  style=cfg.get("style", "sift"),
-                                                  code_kind=_ffi.CODE_RABITQ if cfg["code_kind"] == "rabitq" else _ffi.CODE_BINARY)
-        log("ground truth (GPU brute force) on a query sample")
-        gq = cfg.get("gt_queries", cfg["n_queries"])
-        gt = brute_force_topk(dti.vectors, queries[:gq], k, cfg["metric"], chunk=1 << 20).cpu().numpy()
-        dev_index = dti.create(local_rank)
-        log(f"index: {dti.centroids.shape[0]} nodes, {dti.n_vectors} vectors, threshold {dti.threshold:.6g}")
-    elif rank == 0:
-        log(f"generating {cfg['label']}: n={cfg['n']} dim={cfg['dim']}")
-        base, queries = synthetic_mixture(cfg["n"], cfg["dim"], seed=0xC0DD1E, device=device, style=cfg["style"],
-                                          n_queries=cfg["n_queries"], latent_dim=cfg["latent_dim"])
-        log("ground truth (GPU brute force)")
-        gt = brute_force_topk(base, queries, k, cfg["metric"]).cpu().numpy()
-        log("building index (GPU k-means tree)")
-        # binary threshold = exact mean: the reference's single-precision running sum saturates long
-        # before 10^9 values (it would give 0.017 instead of ~0.4 here and set every code bit)
-        fi = build_index(base, cfg["branching"], cfg["leaf"], cfg["metric"], 20, seed=1, code_kind=cfg["code_kind"],
-                         threshold=args.threshold if args.threshold != "reference" else None)
-        ls = fi.leaf_sizes()
-        log(f"index: {fi.n_nodes} nodes, {len(ls)} leaves (min {ls.min()}, mean {ls.mean():.1f}, max {ls.max()}), "
-            f"{fi.n_levels()} levels, threshold {fi.threshold:.6g}")
-        del base
+    out = run_config(args.config, args, rank, world, local_rank, device, backend, args.steps, args.warmup,
+                     want_cpu=not args.no_cpu_baseline, want_filter=True)
+    if rank == 0 and world == 1 and args.config == "gist1m" and not args.no_hbm_probe and not args.n:
+        # the same kernels where the codes cannot sit in the Infinity Cache: 10M x 960, 1.2 GB of codes
         torch.cuda.empty_cache()
-    else:
-        queries = torch.empty((cfg["n_queries"], cfg["dim"]), dtype=torch.float32, device=device)
-    if world > 1:
-        dist.broadcast(queries, src=0)
-        fi = broadcast_flat(fi, 0, device)
-    if dev_index is None:
-        shard = fi.shard(rank, world)
-        dev_index = DeviceIndex(shard, local_rank)
-    log(f"setup {time.perf_counter() - t_setup:.1f} s; device bytes {dev_index.device_bytes / 1e9:.2f} GB")
-
-    flags = _ffi.SEARCH_TIME_STAGES
-    nq = queries.shape[0]
-    out_ids = torch.empty((nq, k), dtype=torch.int64, device=device)
-    out_dist = torch.empty((nq, k), dtype=torch.float32, device=device)
-    out_cnt = torch.empty((nq,), dtype=torch.int32, device=device)
-    rf_box = [cfg["rerank_sweep"][0]]
-
-    def local_search(q, kk, pp, rr):
-        return dev_index.search_batch_device(q, kk, pp, rr, flags, out_ids, out_dist, out_cnt)
-
-    class _ShardEngine:  # this rank's shard behind the three-step interface, stage timing on
-        def shard_scan(self, q, kk, pp, rr, leaves=None, leaf_count=None):
-            return dev_index.shard_scan(q, kk, pp, rr, flags, leaves=leaves, leaf_count=leaf_count)
-
-        def route_device(self, q, pp, out=None):
-            return dev_index.route_device(q, pp, flags, out=out)
-
-        leaf_stride = staticmethod(dev_index.leaf_stride)
-        packed_len = staticmethod(dev_index.packed_len)
-
-        shard_ties = staticmethod(dev_index.shard_ties)
-        shard_finish = staticmethod(dev_index.shard_finish)
-
-    exact = world > 1 and args.sharded == "exact"
-    # CUDDLE_BENCH_SHARD_ROUTING=0: every rank routes the whole batch (A/B against routing a slice each + all-gather)
-    searcher = (ExactShardedSearcher(_ShardEngine(), shard_routing=os.environ.get("CUDDLE_BENCH_SHARD_ROUTING", "1") != "0")
-                if exact else ShardedSearcher(local_search))
-
-    def step():
-        trace("step: search")
-        out = searcher.search_batch(queries, k, probes, rf_box[0])
-        if world > 1 and backend != "nccl":
-            torch.cuda.synchronize()  # rehearsal backends stage CUDA tensors through the host on their own streams
-        trace("step: done")
-        return out
-
-    # ---- operating point: cheapest sweep point with recall@10 >= 0.95 ------------------------
-    sweep = []
-    chosen = None
-    for rf in ([args.rerank] if args.rerank else cfg["rerank_sweep"]):
-        rf_box[0] = rf
-        ids, _, _ = step()
-        torch.cuda.synchronize()
-        if rank == 0:
-            r = recall_at_k(ids.cpu().numpy()[:len(gt)], gt, k)
-            sweep.append((rf, r))
-            log(f"probes={probes} rerank_factor={rf}: recall@{k} = {r:.4f}")
-        flag = torch.tensor([1 if (rank == 0 and sweep[-1][1] >= 0.95) else 0], device=device)
-        if world > 1:
-            dist.broadcast(flag, src=0)
-        if int(flag.item()):
-            chosen = rf
-            break
-    if chosen is None:
-        chosen = (args.rerank or cfg["rerank_sweep"][-1])
-    rf_box[0] = chosen
-    trace(f"operating point rf={chosen}")
-    dev_index.stage_times()  # drop the sweep's timings
-    trace("sweep timings dropped")
-
-    # ---- timed region ---------------------------------------------------------------------------
-    for _ in range(args.warmup):
-        step()
-    dev_index.stage_times()
-    trace("warm-up done")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    trace("timed region starts")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    trace("timed region done")
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    stage = dev_index.stage_times()
-    stats = dev_index.last_stats()
-    trace("stage times read")
-
-    # per-batch latency distribution (separate loop: one sync per batch)
-    lat = []
-    for _ in range(max(args.steps, 20)):
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        step()
-        torch.cuda.synchronize()
-        lat.append((time.perf_counter() - t1) * 1e3)
-    lat.sort()
-    dev_index.stage_times()
-
-    ids, _, _ = step()  # every rank: the search is collective
-    torch.cuda.synchronize()
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    recall = recall_at_k(ids.cpu().numpy()[:len(gt)], gt, k)
-
-    # ---- roofline of the dominant kernel (the Hamming scan + select) -----------------------------
-    rabitq = cfg["code_kind"] == "rabitq"
-    code_bytes = (4 * ((cfg["dim"] + 31) // 32) + 8) if rabitq else 8 * ((cfg["dim"] + 63) // 64)
-    scan_kernel = "scan_select_rabitq_kernel" if rabitq else "scan_select_hamming_kernel"
-    scan_bytes = stats["vectors_scanned"] * code_bytes           # algorithmic bytes of one launch (this rank)
-    rerank_bytes = stats["vectors_reranked"] * 4 * cfg["dim"]
-    n_timed = max(stage["searches"], 1)
-    scan_ms = stage["scan"] / n_timed
-    achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", f"pmc_hbm_traffic_{args.config}.json")
-    if world == 1 and os.path.exists(pmc_path):  # measured separately under rocprofv3 --pmc (it cannot run inside this process)
-        pmc = json.load(open(pmc_path))
-        traffic = pmc["kernels"].get(scan_kernel, {}).get("traffic_bytes_per_launch")
-        traffic_src = os.path.relpath(pmc_path, ROOT)
-    roofline = dict(bound="hbm", kernel=scan_kernel, achieved=achieved, peak=HBM_PEAK_GBPS,
-                    unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=traffic, traffic_source=traffic_src,
-                    algorithmic_bytes_per_launch=scan_bytes, avg_launch_ms=scan_ms,
-                    stage_ms_per_step={n: stage[n] / n_timed for n in _ffi.STAGE_NAMES},
-                    rerank_GBps=(rerank_bytes / (stage["rerank"] / n_timed * 1e-3) / 1e9) if stage["rerank"] > 0 else 0.0,
-                    code_array_bytes=cfg["n"] * code_bytes,
-                    note=("the whole code array fits the 256 MiB Infinity Cache, so re-reads across queries may be served "
-                          "on-die; " if cfg["n"] * code_bytes <= (256 << 20) else
-                          "the code array is larger than the 256 MiB Infinity Cache; ") +
-                         "achieved = algorithmic bytes per second, traffic = HBM bytes per launch from the PMC counters")
-
-    # routing filter: approximate (matrix-core) distances against the error bound its proof uses
-    route_filter = []
-    if world == 1:
-        q_host = queries[:256].cpu().numpy()
-        for level in range(dev_index.levels):
-            try:
-                ratio, err = dev_index.route_filter_error(q_host, probes, level)
-                route_filter.append({"level": level, "max_err_over_bound": ratio, "max_abs_err": err})
-            except _ffi.CuddleError:
-                pass  # narrow level (exact kernels only) or never a whole frontier
-
-    cpu = None
-    if not args.no_cpu_baseline and fi is not None:
-        log("CPU baseline (oracle port, OpenMP)")
-        cpu, cpu_ids, sample = cpu_baseline(fi, queries.cpu().numpy(), k, probes, chosen)
-        same = bool(np.array_equal(cpu_ids[:sample].astype(np.int64), ids.cpu().numpy()[:sample])) if (world == 1 or exact) else None
-        cpu["gpu_ids_identical_on_sample"] = same
-
-    total_q = nq * args.steps
-    out = {
-        "metric": f"batched QPS at recall@{k}>=0.95",
-        "value": total_q / elapsed,
-        "unit": "queries/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "f32 sign-masked sums (RaBitQ estimator) + f32 rerank" if rabitq else "u64 xor/popcount scan + f32 rerank",
-        "data": "synthetic",
-        "config": {"workload": cfg["label"] + f", {cfg['metric']}, k={k}, {nq}-query batch, probes_per_level={probes}, "
-                               f"rerank_factor={chosen}" + (f", branching {cfg['branching']} / leaf {cfg['leaf']}" if "branching" in cfg else ""),
-                   "name": args.config, "binary_threshold": args.threshold,
-                   "parallelism": (f"leaf-sharded x{world}, {args.sharded} selection" if world > 1 else "single GPU")},
-        f"recall_at_{k}": recall,
-        "recall_sweep": sweep,
-        "p50_batch_ms": lat[len(lat) // 2],
-        "p99_batch_ms": lat[min(len(lat) - 1, len(lat) * 99 // 100)],
-        "candidates_per_query": stats["vectors_scanned"] / nq,
-        "leaves_per_query": stats["leaves_searched"] / nq,
-        "reranked_per_query": stats["vectors_reranked"] / nq,
-        "route_fallbacks_per_batch": stats["route_fallbacks"],
-        "route_filter": route_filter,
-        "max_candidates": stats["max_candidates"],
-        "roofline": roofline,
-        "cpu_baseline": cpu,
-    }
-    print(json.dumps(out), flush=True)
+        log("HBM-resident probe: gist10m")
+        big = run_config("gist10m", args, rank, world, local_rank, device, backend, max(5, min(args.steps, 20)), 3,
+                         want_cpu=False, want_filter=False)
+        r = dict(big["roofline"])
+        r.update(workload=big["config"]["workload"], value=big["value"], unit=big["unit"], ms_per_step=big["ms_per_step"],
+                 recall_at_10=big["recall_at_10"], candidates_per_query=big["candidates_per_query"])
+        out["roofline_hbm_resident"] = r
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -19,8 +19,15 @@
  *   - every function returns a cuddle_status; cuddle_last_error() gives the message of the
  *     last failure on the calling thread; the library never aborts the process
  *     (the reference panics/aborts: hierarchical.rs:337,402; Cargo.toml:54);
- *   - a handle may be used from several threads, but calls on ONE handle are serialised by
- *     an internal mutex (they share the handle's workspace).
+ *   - a handle may be used from several threads: an internal mutex serialises the calls while
+ *     they ENQUEUE. A handle has one work space, so batches of one handle never overlap on the
+ *     GPU either: a call that names another stream than the handle's previous call first waits,
+ *     on the host, for that previous stream (use one stream per handle to avoid the wait, and
+ *     several handles - e.g. shards - for concurrent batches);
+ *   - limits (CUDDLE_ERR_UNSUPPORTED beyond them): dim <= 32768; fewer than 2^32 vectors per
+ *     handle; at most 262144 vectors in one leaf; fewer than 2^25 candidates per query
+ *     (leaf-list capacity x largest leaf); probes_per_level <= 4096 when a level is wider than
+ *     4096 nodes; k * rerank_factor <= 16384 in the (uncapped) stats variant.
  */
 #ifndef CUDDLE_HIP_H
 #define CUDDLE_HIP_H
@@ -42,7 +49,8 @@ typedef enum cuddle_status {
     CUDDLE_ERR_NO_DEVICE = 4, /* no gfx950 device visible */
     CUDDLE_ERR_OOM = 5,       /* device or host allocation failed */
     CUDDLE_ERR_BAD_INDEX = 6, /* index description is inconsistent (offsets not monotone, ids out of range ...) */
-    CUDDLE_ERR_UNSUPPORTED = 7 /* valid in the reference but outside this build's limits (documented per call) */
+    CUDDLE_ERR_UNSUPPORTED = 7, /* valid in the reference but outside this build's limits (documented per call) */
+    CUDDLE_ERR_RCCL = 8        /* RCCL could not be loaded, or a collective failed */
 } cuddle_status;
 
 /* DistanceMetric, src/distance/mod.rs:10-17. Returned distances follow distance() (:23-34):
@@ -178,6 +186,32 @@ cuddle_status cuddle_search_batch_device(cuddle_index *idx, const float *d_queri
                                          uint32_t flags, uint64_t *d_out_ids, float *d_out_dist,
                                          uint32_t *d_out_count, void *stream);
 
+/* Batched search_with_stats (hierarchical.rs:831-938): the always-sorting variant of the search
+ * (every level stably sorted, routing always by the index metric, no 10000 cap) together with
+ * what SearchStats (:36-45) records for each query. Host pointers; row q of every output
+ * belongs to query q:
+ *   out_ids / out_dist [n][k], out_count [n]        the results, as cuddle_search_batch
+ *   out_leaves [n][leaf_stride], out_leaf_count [n]  leaves_searched_ids in accumulation order
+ *                                                    (:902, :917) and leaves_searched (:916);
+ *                                                    leaf_stride >= cuddle_index_leaf_stride()
+ *   out_level_nodes [n][level_stride], out_level_count [n]
+ *                                                    probes_per_level (:861): the frontier size at
+ *                                                    the top of every loop iteration, including the
+ *                                                    empty frontier that ends the loop;
+ *                                                    level_stride >= cuddle_index_levels() + 1
+ *   out_scanned [n]                                  vectors_scanned_binary (:920-922)
+ *   out_reranked [n]                                 vectors_reranked_full (:927-928)
+ * total_leaves, total_vectors and tree_depth are properties of the index (cuddle_index_levels()
+ * - 1 is the depth of the deepest node). */
+cuddle_status cuddle_search_batch_with_stats(cuddle_index *idx, const float *queries,
+                                             uint32_t n_queries, uint32_t dim, uint32_t k,
+                                             uint32_t probes, uint32_t rerank_factor,
+                                             uint64_t *out_ids, float *out_dist, uint32_t *out_count,
+                                             uint32_t *out_leaves, uint32_t leaf_stride,
+                                             uint32_t *out_leaf_count, uint32_t *out_level_nodes,
+                                             uint32_t level_stride, uint32_t *out_level_count,
+                                             uint32_t *out_scanned, uint32_t *out_reranked);
+
 /* Stats of the most recent search on this handle (synchronises the handle's last stream). */
 cuddle_status cuddle_last_stats(cuddle_index *idx, cuddle_stats *stats);
 /* Per-stage device time in milliseconds, summed over every search on this handle that ran with
@@ -239,9 +273,7 @@ cuddle_status cuddle_route_filter_error(cuddle_index *idx, const float *queries,
 /* The same on device pointers, enqueued on `stream` (1..4096 queries per call): d_leaves
  * [n_queries][leaf_stride] and d_leaf_count [n_queries] receive the leaf lists. leaf_stride
  * must be at least cuddle_index_leaf_stride(probes_per_level), the capacity every search with
- * that probes_per_level uses for its leaf lists (it depends on the tree only). The lists are
- * copied out of the handle's workspace asynchronously: the next call on the handle must use
- * the same stream. */
+ * that probes_per_level uses for its leaf lists (it depends on the tree only). */
 cuddle_status cuddle_index_leaf_stride(const cuddle_index *idx, uint32_t probes_per_level,
                                        uint32_t *out);
 cuddle_status cuddle_route_batch_device(cuddle_index *idx, const float *d_queries,
@@ -349,6 +381,33 @@ cuddle_status cuddle_merge_topk_ordered_device(const uint64_t *d_lists_ids, cons
                                                uint64_t list_stride_bytes, uint64_t *d_out_ids,
                                                float *d_out_dist, uint32_t *d_out_count,
                                                void *stream);
+
+/* ---- leaf-sharded search over the GPUs of one node (RCCL over xGMI) ---------------------------
+ * No counterpart in the reference (a single process; sharding is prose only,
+ * docs/goals/SCALING_GOALS.md:139-147). One process per GPU: each holds one leaf shard of the
+ * index (the whole tree, the vectors of its own leaves) as a cuddle_index and one communicator.
+ * Rank 0 makes the id, the host application hands it to the other ranks (its own channel: a
+ * file, a socket, MPI ...), every rank calls cuddle_comm_init. RCCL is loaded on first use;
+ * CUDDLE_ERR_RCCL when it is missing or a collective fails. */
+#define CUDDLE_COMM_ID_BYTES 128
+typedef struct cuddle_comm cuddle_comm;
+cuddle_status cuddle_comm_unique_id(uint8_t *id /* [CUDDLE_COMM_ID_BYTES] */);
+cuddle_status cuddle_comm_init(int rank, int world, const uint8_t *id, int device_id, cuddle_comm **out);
+void cuddle_comm_destroy(cuddle_comm *comm);
+int cuddle_comm_rank(const cuddle_comm *comm);
+int cuddle_comm_world(const cuddle_comm *comm);
+/* cuddle_search_batch_device of the WHOLE index, computed by all ranks together (every rank calls
+ * it with the same queries and parameters and receives the same result, which is the unsharded
+ * index's result bit for bit): routing split by queries + all-gather of the leaf lists,
+ * cuddle_shard_scan_leaves + all-reduce of the Hamming histograms, cuddle_shard_ties +
+ * all-reduce of the tie counts, cuddle_shard_finish + all-gather of the local top-k,
+ * cuddle_merge_topk_ordered_device. Everything is enqueued on `stream`. Binary codes;
+ * 1..4096 queries; k <= 64 and world * k <= 1024. */
+cuddle_status cuddle_sharded_search_batch(cuddle_index *shard, cuddle_comm *comm, const float *d_queries,
+                                          uint32_t n_queries, uint32_t dim, uint32_t k,
+                                          uint32_t probes_per_level, uint32_t rerank_factor,
+                                          uint32_t flags, uint64_t *d_out_ids, float *d_out_dist,
+                                          uint32_t *d_out_count, void *stream);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,9 @@ namespace cuddle {
 
 enum class DistanceMetric : uint32_t { L2 = CUDDLE_METRIC_L2, Cosine = CUDDLE_METRIC_COSINE, DotProduct = CUDDLE_METRIC_DOT }; // src/distance/mod.rs:10-17
 
-// SearchStats (hierarchical.rs:36-45). probes_per_level is the argument repeated tree_depth times there.
+// SearchStats (hierarchical.rs:36-45), field for field: leaves_searched_ids in accumulation order (:917),
+// probes_per_level = the frontier size at every level including the empty frontier that ends the loop (:861),
+// tree_depth = depth of the deepest node (the reference's max_depth, :851).
 struct SearchStats {
     size_t total_leaves = 0;
     size_t leaves_searched = 0;
@@ -159,23 +161,29 @@ public:
     // search_with_stats (hierarchical.rs:831-938): the always-sorting variant plus its counters.
     std::pair<Result, SearchStats> search_with_stats(const std::vector<float> &query, size_t k, size_t probes_per_level,
                                                      size_t rerank_factor) const {
-        cuddle_stats st;
-        std::memset(&st, 0, sizeof(st));
-        Result r = std::move(search_batch(query.data(), 1, query.size(), k, probes_per_level, rerank_factor,
-                                          CUDDLE_SEARCH_STATS_VARIANT, &st)[0]);
+        if (query.size() != dimension_) throw std::invalid_argument("Query dimension mismatch"); // hierarchical.rs:838
+        uint32_t lstride = 0;
+        check(cuddle_index_leaf_stride(handle_, (uint32_t)probes_per_level, &lstride));
+        const uint32_t levels = cuddle_index_levels(handle_);
+        std::vector<uint64_t> ids(k);
+        std::vector<float> dist(k);
+        std::vector<uint32_t> leaves(lstride), level_nodes(levels + 1);
+        uint32_t count = 0, n_leaves = 0, n_levels = 0, scanned = 0, reranked = 0;
+        check(cuddle_search_batch_with_stats(handle_, query.data(), 1, (uint32_t)query.size(), (uint32_t)k,
+                                             (uint32_t)probes_per_level, (uint32_t)rerank_factor, ids.data(), dist.data(), &count,
+                                             leaves.data(), lstride, &n_leaves, level_nodes.data(), levels + 1, &n_levels,
+                                             &scanned, &reranked));
+        Result r;
+        for (uint32_t i = 0; i < count; ++i) r.emplace_back((size_t)ids[i], dist[i]);
         SearchStats out;
         out.total_leaves = leaves_;
         out.total_vectors = len_;
-        out.leaves_searched = st.leaves_searched;
-        out.vectors_scanned_binary = st.vectors_scanned;
-        out.vectors_reranked_full = st.vectors_reranked;
-        out.tree_depth = st.tree_levels;
-        out.probes_per_level.assign(out.tree_depth, probes_per_level);
-        std::vector<uint32_t> leaves(std::max<size_t>(st.leaves_searched, 1));
-        uint32_t n = 0;
-        check(cuddle_route_batch(handle_, query.data(), 1, (uint32_t)query.size(), (uint32_t)probes_per_level,
-                                 CUDDLE_SEARCH_STATS_VARIANT, leaves.data(), (uint32_t)leaves.size(), &n));
-        out.leaves_searched_ids.assign(leaves.begin(), leaves.begin() + std::min<size_t>(n, leaves.size()));
+        out.leaves_searched = n_leaves;
+        out.leaves_searched_ids.assign(leaves.begin(), leaves.begin() + n_leaves);
+        out.vectors_scanned_binary = scanned;
+        out.vectors_reranked_full = reranked;
+        out.tree_depth = max_depth();
+        out.probes_per_level.assign(level_nodes.begin(), level_nodes.begin() + n_levels);
         return {std::move(r), std::move(out)};
     }
 

@@ -4,6 +4,7 @@
 //   host_mirror_test <index.cfi> <cases.bin>
 // cases.bin: u32 n_queries, dim, k, probes, rerank_factor, stats_variant; f32 queries[nq][dim];
 //            u32 count[nq]; u64 ids[nq][k]; f32 dist[nq][k]  (expected)
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -36,7 +37,12 @@ int main(int argc, char **argv) {
             if (stats) {
                 auto rs = index.search_with_stats(one, k, probes, rf);
                 r = rs.first;
-                if (rs.second.leaves_searched != rs.second.leaves_searched_ids.size() || rs.second.total_vectors != index.len()) bad = 1;
+                const cuddle::SearchStats &st = rs.second;
+                if (st.leaves_searched != st.leaves_searched_ids.size() || st.total_vectors != index.len()) bad = 1;
+                // hierarchical.rs:861: one entry per loop iteration, the roots first, the empty frontier last
+                if (st.probes_per_level.empty() || st.probes_per_level.front() != flat.roots.size() || st.probes_per_level.back() != 0) bad = 1;
+                if (st.tree_depth != index.max_depth() || st.total_leaves != index.count_leaves()) bad = 1;
+                if (st.vectors_reranked_full != std::min<size_t>((size_t)k * rf, st.vectors_scanned_binary)) bad = 1;
             } else {
                 r = index.search(one, k, probes, rf);
             }

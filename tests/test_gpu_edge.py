@@ -102,6 +102,7 @@ def test_fewer_results_than_k_and_single_leaf(gpu):
     assert len(r) == 5 and all(r[i][1] <= r[i + 1][1] for i in range(4))
     r2, st = ci.search_with_stats(q[0], 5, 1, 1)
     assert st.total_leaves == 1 and st.leaves_searched == 1 and st.vectors_scanned_binary == 40
+    assert st.leaves_searched_ids == [0] and st.probes_per_level == [1, 0]
 
 
 def test_empty_leaves_and_shards(gpu):

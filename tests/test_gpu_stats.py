@@ -1,0 +1,88 @@
+"""GPU: search_with_stats (reference: src/index/hierarchical.rs:831-938) through the C ABI and both host
+mirrors. SearchStats must carry what the reference records: leaves_searched_ids in accumulation
+order (:917), the frontier size at every level including the empty frontier that ends the loop
+(:861), vectors scanned (:920-922) and reranked (:927-928, no 10 000 cap). Checked against the
+oracle's trace of the same variant."""
+import numpy as np
+import pytest
+
+from vectordb_amd import _ffi
+from vectordb_amd.index import ClusteredIndex, ClusteredIndexWithRaBitQ, DeviceIndex
+
+from helpers import clustered, queries_like, small_index
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import oracle as orc
+    return orc
+
+
+def _check_stats(fi, gpu, q, k, probes, rf, cls=ClusteredIndex):
+    orc = _oracle()
+    oi = orc.OracleIndex(fi)
+    ci = cls(fi, gpu)
+    results, stats = ci.search_batch_with_stats(q, k, probes, rf)
+    total_leaves = int(fi.is_leaf().sum())
+    for i in range(q.shape[0]):
+        t = oi.search(q[i], k, probes, rf, _ffi.SEARCH_STATS_VARIANT, trace=True)
+        assert t["rc"] == 0
+        st = stats[i]
+        assert st.leaves_searched_ids == [int(v) for v in t["leaves"]], i
+        assert st.leaves_searched == len(t["leaves"])
+        assert st.probes_per_level == [int(v) for v in t["frontier_sizes"]], (i, st.probes_per_level, t["frontier_sizes"])
+        assert st.probes_per_level[0] == fi.n_roots and st.probes_per_level[-1] == 0
+        assert st.vectors_scanned_binary == len(t["cand_pos"])
+        assert st.vectors_reranked_full == len(t["sel_pos"]) == min(k * rf, len(t["cand_pos"]))
+        assert st.total_leaves == total_leaves and st.total_vectors == fi.n_vectors
+        assert st.tree_depth == fi.n_levels() - 1
+        n = t["count"]
+        assert [r[0] for r in results[i]] == [int(v) for v in t["ids"][:n]]
+        assert np.array_equal(np.array([r[1] for r in results[i]], dtype=np.float32).view(np.uint32), t["dist"][:n].view(np.uint32))
+    # the one-query form returns the same thing
+    r0, s0 = ci.search_with_stats(q[0], k, probes, rf)
+    assert r0 == results[0] and s0 == stats[0]
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+def test_search_with_stats_matches_oracle(gpu, metric):
+    x, fi = small_index(n=6000, d=48, n_clusters=40, branching=8, leaf=40, metric=metric)
+    q = queries_like(x, 40, 3)
+    _check_stats(fi, gpu, q, 10, 4, 5)
+    _check_stats(fi, gpu, q, 10, 1, 1)
+    _check_stats(fi, gpu, q, 100, 6, 200)   # k * rf = 20000 > 10000: the stats variant has no cap (:927)
+
+
+def test_search_with_stats_unbalanced_tree_and_rabitq(gpu):
+    # three levels with leaves at different depths: frontiers shrink to zero at different levels per query
+    x = clustered(30000, 24, 150, 5, sigma=0.25)
+    from vectordb_amd.builder import build_index
+    fi = build_index(x, 12, 25, "l2", 6, seed=7)
+    assert fi.n_levels() >= 3
+    q = queries_like(x, 60, 9, noise=0.1)
+    _check_stats(fi, gpu, q, 10, 3, 4)
+    _check_stats(fi, gpu, q, 10, 40, 4)
+    x, fi = small_index(n=4000, d=64, n_clusters=30, branching=8, leaf=30, metric="l2", code_kind="rabitq")
+    _check_stats(fi, gpu, queries_like(x, 24, 2), 10, 4, 6, cls=ClusteredIndexWithRaBitQ)
+
+
+def test_stats_single_leaf_and_empty(gpu):
+    from vectordb_amd.builder import build_index
+    x = clustered(40, 12, 2, 3)
+    fi = build_index(x, 4, 30, "l2", 5, seed=1)
+    assert fi.n_nodes == 1
+    ci = ClusteredIndex(fi, gpu)
+    r, st = ci.search_with_stats(x[0], 5, 1, 1)
+    assert st.total_leaves == 1 and st.leaves_searched == 1 and st.leaves_searched_ids == [0]
+    assert st.vectors_scanned_binary == 40 and st.vectors_reranked_full == 5 and st.probes_per_level == [1, 0]
+    assert st.tree_depth == 0 and len(r) == 5
+    # argument checks of the entry point
+    dev = DeviceIndex(fi, gpu)
+    q = np.ascontiguousarray(x[:2])
+    out = [np.zeros((2, 5), np.uint64), np.zeros((2, 5), np.float32), np.zeros(2, np.uint32), np.zeros((2, 4), np.uint32),
+           np.zeros(2, np.uint32), np.zeros((2, 1), np.uint32), np.zeros(2, np.uint32), np.zeros(2, np.uint32), np.zeros(2, np.uint32)]
+    st = dev._lib.cuddle_search_batch_with_stats(dev._handle, _ffi.ptr(q), 2, 12, 5, 1, 1, _ffi.ptr(out[0]), _ffi.ptr(out[1]),
+                                                 _ffi.ptr(out[2]), _ffi.ptr(out[3]), 4, _ffi.ptr(out[4]), _ffi.ptr(out[5]), 1,
+                                                 _ffi.ptr(out[6]), _ffi.ptr(out[7]), _ffi.ptr(out[8]))
+    assert st == _ffi.ERR_BAD_ARG  # level_stride < levels + 1

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("CUDDLE_HIP_LIB") or os.path.join(_HERE, "libcuddle_hi
 
 ABI_VERSION = 1
 
-OK, ERR_BAD_ARG, ERR_BAD_DIM, ERR_HIP, ERR_NO_DEVICE, ERR_OOM, ERR_BAD_INDEX, ERR_UNSUPPORTED = range(8)
+OK, ERR_BAD_ARG, ERR_BAD_DIM, ERR_HIP, ERR_NO_DEVICE, ERR_OOM, ERR_BAD_INDEX, ERR_UNSUPPORTED, ERR_RCCL = range(9)
 STATUS_NAMES = {
     OK: "CUDDLE_OK",
     ERR_BAD_ARG: "CUDDLE_ERR_BAD_ARG",
@@ -27,6 +27,7 @@ STATUS_NAMES = {
     ERR_OOM: "CUDDLE_ERR_OOM",
     ERR_BAD_INDEX: "CUDDLE_ERR_BAD_INDEX",
     ERR_UNSUPPORTED: "CUDDLE_ERR_UNSUPPORTED",
+    ERR_RCCL: "CUDDLE_ERR_RCCL",
 }
 
 METRIC_L2, METRIC_COSINE, METRIC_DOT = 0, 1, 2
@@ -102,6 +103,8 @@ SIGNATURES = {
     "cuddle_index_reserve": (_int, [_vp, _u32, _u32, _u32, _u32]),
     "cuddle_search_batch": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(Stats)]),
     "cuddle_search_batch_device": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "cuddle_search_batch_with_stats": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u32,
+                                              _vp, _vp, _vp]),
     "cuddle_last_stats": (_int, [_vp, C.POINTER(Stats)]),
     "cuddle_stage_times": (_int, [_vp, _vp, _vp]),
     "cuddle_distance_pairs": (_int, [_vp, _vp, _u64, _u32, _u32, _vp, _int]),
@@ -129,6 +132,12 @@ SIGNATURES = {
     "cuddle_shard_ties": (_int, [_vp, _vp, _vp, _vp]),
     "cuddle_shard_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cuddle_merge_topk_ordered": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "cuddle_comm_unique_id": (_int, [_vp]),
+    "cuddle_comm_init": (_int, [_int, _int, _vp, _int, C.POINTER(_vp)]),
+    "cuddle_comm_destroy": (None, [_vp]),
+    "cuddle_comm_rank": (_int, [_vp]),
+    "cuddle_comm_world": (_int, [_vp]),
+    "cuddle_sharded_search_batch": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     "cuddle_merge_topk_ordered_device": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u64, _vp, _vp, _vp, _vp]),
 }
 

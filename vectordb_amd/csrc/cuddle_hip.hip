@@ -121,6 +121,7 @@ struct Plan {
     uint32_t *thr = nullptr;
     uint64_t *sel_ord = nullptr;
     float *qnorm = nullptr; // cosine: sqrt(dot(q, q)) per query
+    uint32_t *level_fc = nullptr; // [n_levels + 1][qc] frontier size of every query at every level (stats variant)
     uint32_t *sel_pos = nullptr, *sel_key = nullptr, *sel_count = nullptr, *cand_count = nullptr;
     float *sel_dist = nullptr;
     // MFMA routing
@@ -166,6 +167,7 @@ struct cuddle_index {
     bool timed = false;
     uint32_t timed_searches = 0;
     hipStream_t last_stream = nullptr;
+    bool stream_used = false; // last_stream names the stream of an earlier call
     uint32_t last_levels = 0;
     // leaf-sharded exact search: the plan of the batch between cuddle_shard_scan and cuddle_shard_finish
     Plan shard_plan;
@@ -181,9 +183,12 @@ struct cuddle_index {
 };
 
 static constexpr uint32_t kMaxChunk = 4096;
+static constexpr size_t kWorkspaceBudget = 3ull << 30; // the handle's work space: chunks shrink before it grows beyond this
 static constexpr size_t kMaxEvents = 1u << 18; // stage-timing events kept between two cuddle_stage_times() calls
 static constexpr uint32_t kScanThreads = 512;
 static constexpr uint32_t kGemmMinWidth = 512; // narrower levels are routed by the exact kernel
+static constexpr uint32_t kMaxLeafVectors = 4096u * 64u; // the scan's tile tables hold the tile number inside a leaf in 12 bits
+static constexpr uint32_t kMaxCandidates = 1u << 25;    // ... and a tile's scan position in 25 bits
 static constexpr uint32_t kLdsDistCap = 24576; // u16 distances kept in LDS per query (48 KiB)
 
 using GroupedKernel = void (*)(IndexDev, const float *, const uint32_t *, uint32_t, const uint32_t *, const uint4 *,
@@ -393,6 +398,8 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
             ix->n_leaves++;
             ix->max_leaf = std::max(ix->max_leaf, cnt);
         }
+        if (cnt > kMaxLeafVectors)
+            return fail(CUDDLE_ERR_UNSUPPORTED, "leaf %u holds %u vectors; at most %u per leaf (split the leaf)", i, cnt, kMaxLeafVectors);
         code_off[i] = (uint32_t)code_units;
         code_units += (uint64_t)(W / 2) * cnt + ((W & 1) ? (cnt + 1) / 2 : 0);
         if (code_units >= (1ull << 32)) return fail(CUDDLE_ERR_UNSUPPORTED, "binary codes exceed 64 GiB per shard");
@@ -547,6 +554,8 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<256, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<256, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<512, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<512, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)grouped_kernel_for(v.dim, v.metric), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -586,9 +595,60 @@ static uint32_t route_margin(uint32_t probes) {
     return std::max<uint32_t>(24, probes / 8);
 }
 
+// Lays the per-chunk arrays of `pl` (strides and qc already set) out from `b`; returns the bytes they take.
+// b == null: sizing only.
+static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
+    const IndexDev &v = ix->dev;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t qc = pl.qc;
+    const size_t dist_bytes = v.code_kind == CUDDLE_CODE_BINARY ? (v.dim < 255 ? 1 : 2) : 4; // u8 / u16 Hamming, f32 estimates
+    size_t o_qcodes = carve(qc * std::max<uint32_t>(v.words, v.dim + 2) * 8); // binary: W u64; RaBitQ: dim+2 floats
+    size_t o_f0 = carve(qc * pl.fstride * 4), o_f1 = carve(qc * pl.fstride * 4);
+    size_t o_fc0 = carve(qc * 4), o_fc1 = carve(qc * 4);
+    size_t o_fd = carve(qc * pl.fstride * 4);
+    size_t o_lv = carve(qc * pl.lstride * 4), o_lc = carve(qc * 4);
+    size_t o_gd = carve(qc * (size_t)pl.cstride * dist_bytes);
+    size_t o_sp = carve(qc * pl.sstride * 4), o_sk = carve(qc * pl.sstride * 4), o_sd = carve(qc * pl.sstride * 4);
+    size_t o_sc = carve(qc * 4), o_cc = carve(qc * 4);
+    size_t o_qcent = carve(qc * split_kp(v.dim) * 4), o_qsq = carve(qc * 4);
+    size_t o_rcp = carve(qc * pl.kc_cap * 4), o_rcd = carve(qc * pl.kc_cap * 4), o_rcm = carve(qc * 4), o_rfl = carve(qc * 4), o_rcc = carve(qc * 4);
+    size_t o_ord = carve(qc * 4);
+    const size_t gw = (size_t)ix->max_parent_width + 1;
+    size_t o_pi = carve(qc * pl.probes * 4), o_pp = carve(qc * pl.probes * 4), o_ps = carve(qc * pl.probes * 4), o_pl = carve(qc * pl.probes * 4);
+    size_t o_sf = carve(qc * 4), o_gc = carve(gw * 4), o_gp = carve(gw * 4), o_gi = carve(gw * 4), o_gf = carve(gw * 4);
+    size_t o_git = carve((qc * pl.probes / kGroupPairs + gw + 1) * 16);
+    size_t o_thr = carve(qc * 8), o_sord = carve(qc * pl.sstride * 8), o_qn = carve(qc * 4);
+    size_t o_lfc = carve(qc * ((size_t)ix->n_levels + 1) * 4);
+    if (!b) return off;
+    pl.qcodes = (uint64_t *)(b + o_qcodes);
+    pl.frontier[0] = (uint32_t *)(b + o_f0); pl.frontier[1] = (uint32_t *)(b + o_f1);
+    pl.fcount[0] = (uint32_t *)(b + o_fc0); pl.fcount[1] = (uint32_t *)(b + o_fc1);
+    pl.fdist = (float *)(b + o_fd);
+    pl.leaves = (uint32_t *)(b + o_lv); pl.lcount = (uint32_t *)(b + o_lc);
+    pl.gdist = (uint16_t *)(b + o_gd);
+    pl.sel_pos = (uint32_t *)(b + o_sp); pl.sel_key = (uint32_t *)(b + o_sk); pl.sel_dist = (float *)(b + o_sd);
+    pl.sel_count = (uint32_t *)(b + o_sc); pl.cand_count = (uint32_t *)(b + o_cc);
+    pl.qcent = (uint16_t *)(b + o_qcent); pl.qsq = (float *)(b + o_qsq);
+    pl.rc_pos = (uint32_t *)(b + o_rcp); pl.rc_dist = (float *)(b + o_rcd); pl.rc_max = (float *)(b + o_rcm);
+    pl.rflag = (uint32_t *)(b + o_rfl); pl.rc_cnt = (uint32_t *)(b + o_rcc);
+    pl.order = (uint32_t *)(b + o_ord);
+    pl.pair_info = (uint32_t *)(b + o_pi); pl.pair_parent = (uint32_t *)(b + o_pp); pl.pair_sorted = (uint32_t *)(b + o_ps); pl.pair_slot = (uint32_t *)(b + o_pl);
+    pl.small_flag = (uint32_t *)(b + o_sf);
+    pl.grp_cnt = (uint32_t *)(b + o_gc); pl.grp_poff = (uint32_t *)(b + o_gp); pl.grp_ioff = (uint32_t *)(b + o_gi);
+    pl.grp_fill = (uint32_t *)(b + o_gf);
+    pl.grp_item = (uint32_t *)(b + o_git);
+    pl.thr = (uint32_t *)(b + o_thr);
+    pl.sel_ord = (uint64_t *)(b + o_sord);
+    pl.qnorm = (float *)(b + o_qn);
+    pl.level_fc = (uint32_t *)(b + o_lfc);
+    return off;
+}
+
 // lstride_min: lower bound for the leaf-list capacity (stage entry points pass their own lists).
+// fixed_base != null: the work space is that device buffer of fixed_cap bytes (nothing is allocated).
 static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32_t probes, uint64_t rerank_k64,
-                               uint32_t lstride_min, Plan &pl) {
+                               uint32_t lstride_min, Plan &pl, void *fixed_base = nullptr, size_t fixed_cap = 0) {
     const IndexDev &v = ix->dev;
     if (probes > kSortCap) {
         // probes beyond every level's width behave as "keep / sort everything"; that is fine as
@@ -617,6 +677,9 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     pl.fstride = (uint32_t)align_up(fmax, 4);
     pl.lstride = (uint32_t)align_up(std::max<uint64_t>(std::min<uint64_t>(lsum, ix->n_leaves), std::max<uint32_t>(lstride_min, 1)), 4);
     uint64_t cbound = std::min<uint64_t>((uint64_t)pl.lstride * ix->max_leaf, v.n_vectors);
+    if (cbound >= kMaxCandidates || pl.lstride >= (1u << 20))
+        return fail(CUDDLE_ERR_UNSUPPORTED, "a query may reach %llu candidates in %u leaves; at most %u candidates per query",
+                    (unsigned long long)cbound, pl.lstride, kMaxCandidates - 1);
     pl.cstride = (uint32_t)align_up(std::max<uint64_t>(cbound, 8), 128); // spill rows never share a cache line
     pl.sstride = (uint32_t)align_up(std::max<uint64_t>(std::min<uint64_t>(pl.rerank_k, cbound), 4), 4);
     pl.tcap = (uint32_t)align_up((size_t)pl.lstride + pl.cstride / 64 + 1, 4);
@@ -636,52 +699,25 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
         pl.scan_lds = rabitq_scan_lds_bytes(v.dim, pl.lstride, pl.tcap, pl.dist_cap);
     }
     if (pl.scan_lds > 150 * 1024) return fail(CUDDLE_ERR_UNSUPPORTED, "leaf list of %u slots does not fit the scan kernel's LDS", pl.lstride);
-    // carve
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t qc = pl.qc;
-    size_t o_qcodes = carve(qc * std::max<uint32_t>(v.words, v.dim + 2) * 8); // binary: W u64; RaBitQ: dim+2 floats
-    size_t o_f0 = carve(qc * pl.fstride * 4), o_f1 = carve(qc * pl.fstride * 4);
-    size_t o_fc0 = carve(qc * 4), o_fc1 = carve(qc * 4);
-    size_t o_fd = carve(qc * pl.fstride * 4);
-    size_t o_lv = carve(qc * pl.lstride * 4), o_lc = carve(qc * 4);
-    size_t o_gd = carve(qc * (size_t)pl.cstride * 4); // u8/u16 Hamming or f32 estimates
-    size_t o_sp = carve(qc * pl.sstride * 4), o_sk = carve(qc * pl.sstride * 4), o_sd = carve(qc * pl.sstride * 4);
-    size_t o_sc = carve(qc * 4), o_cc = carve(qc * 4);
     pl.kc_cap = (uint32_t)align_up((size_t)pl.probes + route_margin(pl.probes), 4); // every candidate costs an exact distance
-    size_t o_qcent = carve(qc * split_kp(v.dim) * 4), o_qsq = carve(qc * 4);
-    size_t o_rcp = carve(qc * pl.kc_cap * 4), o_rcd = carve(qc * pl.kc_cap * 4), o_rcm = carve(qc * 4), o_rfl = carve(qc * 4), o_rcc = carve(qc * 4);
-    size_t o_ord = carve(qc * 4);
-    const size_t gw = (size_t)ix->max_parent_width + 1;
-    size_t o_pi = carve(qc * pl.probes * 4), o_pp = carve(qc * pl.probes * 4), o_ps = carve(qc * pl.probes * 4), o_pl = carve(qc * pl.probes * 4);
-    size_t o_sf = carve(qc * 4), o_gc = carve(gw * 4), o_gp = carve(gw * 4), o_gi = carve(gw * 4), o_gf = carve(gw * 4);
-    size_t o_git = carve((qc * pl.probes / kGroupPairs + gw + 1) * 16);
-    size_t o_thr = carve(qc * 8), o_sord = carve(qc * pl.sstride * 8), o_qn = carve(qc * 4);
-    pl.bytes = off;
-    ST_TRY(ix->ws.ensure(pl.bytes));
-    char *b = static_cast<char *>(ix->ws.p);
-    pl.qcodes = (uint64_t *)(b + o_qcodes);
-    pl.frontier[0] = (uint32_t *)(b + o_f0); pl.frontier[1] = (uint32_t *)(b + o_f1);
-    pl.fcount[0] = (uint32_t *)(b + o_fc0); pl.fcount[1] = (uint32_t *)(b + o_fc1);
-    pl.fdist = (float *)(b + o_fd);
-    pl.leaves = (uint32_t *)(b + o_lv); pl.lcount = (uint32_t *)(b + o_lc);
-    pl.gdist = (uint16_t *)(b + o_gd);
-    pl.sel_pos = (uint32_t *)(b + o_sp); pl.sel_key = (uint32_t *)(b + o_sk); pl.sel_dist = (float *)(b + o_sd);
-    pl.sel_count = (uint32_t *)(b + o_sc); pl.cand_count = (uint32_t *)(b + o_cc);
-    pl.qcent = (uint16_t *)(b + o_qcent); pl.qsq = (float *)(b + o_qsq);
-    pl.rc_pos = (uint32_t *)(b + o_rcp); pl.rc_dist = (float *)(b + o_rcd); pl.rc_max = (float *)(b + o_rcm);
-    pl.rflag = (uint32_t *)(b + o_rfl); pl.rc_cnt = (uint32_t *)(b + o_rcc);
-    pl.order = (uint32_t *)(b + o_ord);
-    pl.pair_info = (uint32_t *)(b + o_pi); pl.pair_parent = (uint32_t *)(b + o_pp); pl.pair_sorted = (uint32_t *)(b + o_ps); pl.pair_slot = (uint32_t *)(b + o_pl);
-    pl.small_flag = (uint32_t *)(b + o_sf);
-    pl.grp_cnt = (uint32_t *)(b + o_gc); pl.grp_poff = (uint32_t *)(b + o_gp); pl.grp_ioff = (uint32_t *)(b + o_gi);
-    pl.grp_fill = (uint32_t *)(b + o_gf);
-    pl.grp_item = (uint32_t *)(b + o_git);
-    pl.thr = (uint32_t *)(b + o_thr);
-    pl.sel_ord = (uint64_t *)(b + o_sord);
-    pl.qnorm = (float *)(b + o_qn);
+    // Chunk size: the per-query rows (above all the spill row of phase-1 distances) times the chunk must fit
+    // the budget - the caller's fixed buffer, or kWorkspaceBudget of device memory for the handle's own.
+    const size_t budget = fixed_base ? fixed_cap : kWorkspaceBudget;
+    while (pl.qc > 1 && carve_plan(ix, pl, nullptr) > budget) pl.qc = (pl.qc + 1) / 2;
+    pl.bytes = carve_plan(ix, pl, nullptr);
+    if (fixed_base) {
+        if (pl.bytes > fixed_cap)
+            return fail(CUDDLE_ERR_UNSUPPORTED, "one query of this search needs %zu bytes of work space; the fixed buffer holds %zu",
+                        pl.bytes, fixed_cap);
+        carve_plan(ix, pl, static_cast<char *>(fixed_base));
+    } else {
+        ST_TRY(ix->ws.ensure(pl.bytes));
+        carve_plan(ix, pl, static_cast<char *>(ix->ws.p));
+    }
     return CUDDLE_OK;
 }
+
+static uint32_t plan_leaf_stride(const cuddle_index *ix, uint32_t probes);
 
 static cuddle_status rerank_k_of(uint32_t k, uint32_t rf, uint32_t flags, uint64_t &out) {
     if (k == 0) return fail(CUDDLE_ERR_BAD_ARG, "k must be >= 1 (the reference underflows k-1, hierarchical.rs:651)");
@@ -695,6 +731,15 @@ static cuddle_status rerank_k_of(uint32_t k, uint32_t rf, uint32_t flags, uint64
 // ---------------------------------------------------------------------------------------------
 // stage launchers (device pointers, asynchronous on `s`)
 // ---------------------------------------------------------------------------------------------
+// A handle has ONE work space: a call on another stream than the previous call's first waits (on the host)
+// for that stream, so that it cannot overwrite the work space of a batch that is still running.
+static cuddle_status enter_stream(cuddle_index *ix, hipStream_t s) {
+    if (ix->stream_used && ix->last_stream != s) HIP_TRY(hipStreamSynchronize(ix->last_stream));
+    ix->last_stream = s;
+    ix->stream_used = true;
+    return CUDDLE_OK;
+}
+
 // Records an event; `stage` names the work enqueued between it and the next event (-1: none).
 static void mark(cuddle_index *ix, hipStream_t s, int stage) {
     if (!ix->timed) return;
@@ -797,6 +842,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
     uint64_t fb = v.n_roots;
     bool grouped = false; // this level's distances come from the (query, parent) pairs of the level above
     for (uint32_t l = 0; l < ix->n_levels; ++l) {
+        if (stats) // SearchStats::probes_per_level (hierarchical.rs:861): the frontier size of every query at this level
+            HIP_TRY(hipMemcpyAsync(pl.level_fc + (size_t)l * pl.qc, pl.fcount[cur], (size_t)nq * 4, hipMemcpyDeviceToDevice, s));
         fb = std::min<uint64_t>(fb, ix->level_width[l]);
         const uint32_t bound = (uint32_t)std::max<uint64_t>(fb, 1);
         const bool keep_all = !stats && bound <= pl.probes;
@@ -935,6 +982,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         grouped = group_next;
         fb = fb_next;
     }
+    if (stats) // what is left below the last level: empty, the frontier on which the reference's loop ends
+        HIP_TRY(hipMemcpyAsync(pl.level_fc + (size_t)ix->n_levels * pl.qc, pl.fcount[cur], (size_t)nq * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
 }
@@ -960,8 +1009,8 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
                            pl.lstride, pl.lcount, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap,
                            reinterpret_cast<float *>(pl.gdist), pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count,
                            pl.cand_count, pl.order);
-        hipLaunchKernelGGL(selection_sort_f32_kernel, dim3(nq), dim3(256), (size_t)host_next_pow2(pl.sstride) * 16, s,
-                           pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count);
+        hipLaunchKernelGGL(selection_sort_f32_kernel, dim3(nq), dim3(256), (size_t)host_next_pow2(pl.sstride) * 8, s,
+                           pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.sel_ord);
         HIP_TRY(hipGetLastError());
         return CUDDLE_OK;
     }
@@ -1006,22 +1055,24 @@ static cuddle_status launch_topk(cuddle_index *ix, const Plan &pl, uint32_t nq, 
 }
 
 // The whole path on device pointers; chunks the batch so the work space stays bounded.
+// fixed_ws != null: the work space is that buffer of fixed_cap bytes and nothing is allocated (no stage timing either:
+// its events are created on demand).
 static cuddle_status search_device_locked(cuddle_index *ix, const float *dq, uint32_t nq, uint32_t dim, uint32_t k,
                                           uint32_t probes, uint32_t rf, uint32_t flags, uint64_t *d_ids, float *d_dist,
-                                          uint32_t *d_count, hipStream_t s) {
+                                          uint32_t *d_count, hipStream_t s, void *fixed_ws = nullptr, size_t fixed_cap = 0) {
     if (!dq || !d_ids || !d_dist) return fail(CUDDLE_ERR_BAD_ARG, "null query or output pointer");
     if (dim != ix->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, ix->dev.dim);
     if (probes == 0) return fail(CUDDLE_ERR_BAD_ARG, "probes_per_level must be >= 1");
     uint64_t rerank_k;
     ST_TRY(rerank_k_of(k, rf, flags, rerank_k));
-    ix->timed = (flags & CUDDLE_SEARCH_TIME_STAGES) != 0 && ix->events_used + 4096 < kMaxEvents;
-    ix->shard_state = 0; // the work space is about to be re-planned: an unfinished sharded batch is void
-    ix->last_stream = s;
+    ix->timed = !fixed_ws && (flags & CUDDLE_SEARCH_TIME_STAGES) != 0 && ix->events_used + 4096 < kMaxEvents;
+    if (!fixed_ws) ix->shard_state = 0; // the work space is about to be re-planned: an unfinished sharded batch is void
+    ST_TRY(enter_stream(ix, s));
     ix->last_levels = ix->n_levels;
     HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
     if (nq == 0) return CUDDLE_OK;
     Plan pl;
-    ST_TRY(make_plan(ix, nq, k, probes, rerank_k, 0, pl));
+    ST_TRY(make_plan(ix, nq, k, probes, rerank_k, 0, pl, fixed_ws, fixed_cap));
     if (ix->timed) ix->timed_searches++;
     for (uint32_t q0 = 0; q0 < nq; q0 += pl.qc) {
         const uint32_t qc = std::min(pl.qc, nq - q0);
@@ -1150,6 +1201,72 @@ extern "C" cuddle_status cuddle_search_batch(cuddle_index *idx, const float *que
     return CUDDLE_OK;
 }
 
+extern "C" cuddle_status cuddle_search_batch_with_stats(cuddle_index *idx, const float *queries, uint32_t n_queries,
+                                                        uint32_t dim, uint32_t k, uint32_t probes, uint32_t rerank_factor,
+                                                        uint64_t *out_ids, float *out_dist, uint32_t *out_count,
+                                                        uint32_t *out_leaves, uint32_t leaf_stride, uint32_t *out_leaf_count,
+                                                        uint32_t *out_level_nodes, uint32_t level_stride,
+                                                        uint32_t *out_level_count, uint32_t *out_scanned,
+                                                        uint32_t *out_reranked) {
+    if (!idx) return fail(CUDDLE_ERR_BAD_ARG, "index is null");
+    if (!queries || !out_ids || !out_dist || !out_count || !out_leaves || !out_leaf_count || !out_level_nodes ||
+        !out_level_count || !out_scanned || !out_reranked)
+        return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    if (dim != idx->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, idx->dev.dim);
+    if (probes == 0) return fail(CUDDLE_ERR_BAD_ARG, "probes must be >= 1");
+    const uint32_t flags = CUDDLE_SEARCH_STATS_VARIANT;
+    uint64_t rerank_k;
+    ST_TRY(rerank_k_of(k, rerank_factor, flags, rerank_k));
+    if (level_stride < idx->n_levels + 1) return fail(CUDDLE_ERR_BAD_ARG, "level_stride %u < tree levels + 1 = %u", level_stride, idx->n_levels + 1);
+    if (leaf_stride < plan_leaf_stride(idx, probes))
+        return fail(CUDDLE_ERR_BAD_ARG, "leaf_stride %u < cuddle_index_leaf_stride() = %u", leaf_stride, plan_leaf_stride(idx, probes));
+    ST_TRY(enter_stream(idx, nullptr));
+    idx->timed = false;
+    idx->shard_state = 0;
+    idx->last_levels = idx->n_levels;
+    HIP_TRY(hipMemsetAsync(idx->d_stats, 0, sizeof(DevStats), nullptr));
+    if (n_queries == 0) return CUDDLE_OK;
+    Plan pl;
+    ST_TRY(make_plan(idx, n_queries, k, probes, rerank_k, 0, pl));
+    HostIO io;
+    ST_TRY(carve_io(idx, pl.qc, dim, k, 0, io, nullptr));
+    const uint32_t L = idx->n_levels;
+    std::vector<uint32_t> lfc((size_t)pl.qc * (L + 1));
+    for (uint32_t q0 = 0; q0 < n_queries; q0 += pl.qc) {
+        const uint32_t qc = std::min(pl.qc, n_queries - q0);
+        HIP_TRY(hipMemcpy(io.q, queries + (uint64_t)q0 * dim, (size_t)qc * dim * 4, hipMemcpyHostToDevice));
+        ST_TRY(launch_quantize(idx, pl, io.q, qc, nullptr));
+        ST_TRY(launch_route(idx, pl, io.q, qc, flags, nullptr));
+        ST_TRY(launch_scan_select(idx, pl, qc, nullptr));
+        ST_TRY(launch_rerank(idx, pl, io.q, qc, nullptr));
+        ST_TRY(launch_topk(idx, pl, qc, io.ids, io.dist, io.count, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        HIP_TRY(hipMemcpy(out_ids + (uint64_t)q0 * k, io.ids, (size_t)qc * k * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_dist + (uint64_t)q0 * k, io.dist, (size_t)qc * k * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_count + q0, io.count, (size_t)qc * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_leaf_count + q0, pl.lcount, (size_t)qc * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy2D(out_leaves + (uint64_t)q0 * leaf_stride, (size_t)leaf_stride * 4, pl.leaves, (size_t)pl.lstride * 4,
+                            (size_t)std::min(pl.lstride, leaf_stride) * 4, qc, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_scanned + q0, pl.cand_count, (size_t)qc * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_reranked + q0, pl.sel_count, (size_t)qc * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy2D(lfc.data(), (size_t)qc * 4, pl.level_fc, (size_t)pl.qc * 4, (size_t)qc * 4, L + 1, hipMemcpyDeviceToHost));
+        for (uint32_t q = 0; q < qc; ++q) {
+            // the reference pushes the frontier size at the top of every loop iteration and leaves the loop on
+            // the first empty one (hierarchical.rs:860-865): the sizes up to and including the first zero
+            uint32_t *row = out_level_nodes + (uint64_t)(q0 + q) * level_stride, n = 0;
+            for (uint32_t l = 0; l <= L; ++l) {
+                const uint32_t sz = lfc[(size_t)l * qc + q];
+                row[n++] = sz;
+                if (sz == 0) break;
+            }
+            out_level_count[q0 + q] = n;
+        }
+    }
+    return CUDDLE_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // stage entry points
 // ---------------------------------------------------------------------------------------------
@@ -1241,6 +1358,7 @@ extern "C" cuddle_status cuddle_route_batch(cuddle_index *idx, const float *quer
     if (dim != idx->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, idx->dev.dim);
     if (probes_per_level == 0) return fail(CUDDLE_ERR_BAD_ARG, "probes_per_level must be >= 1");
     if (n_queries == 0) return CUDDLE_OK;
+    ST_TRY(enter_stream(idx, nullptr));
     Plan pl;
     ST_TRY(make_plan(idx, n_queries, 1, probes_per_level, 1, 0, pl));
     HostIO io;
@@ -1276,6 +1394,7 @@ extern "C" cuddle_status cuddle_route_filter_error(cuddle_index *idx, const floa
         return fail(CUDDLE_ERR_UNSUPPORTED, "level %u has no contraction operands (narrower than %u nodes)", level, kGemmMinWidth);
     *out_max_ratio = *out_max_abs = 0.f;
     if (n_queries == 0) return CUDDLE_OK;
+    ST_TRY(enter_stream(idx, nullptr));
     Plan pl;
     ST_TRY(make_plan(idx, n_queries, 1, probes_per_level, 1, 0, pl));
     const LevelGemm &g = idx->lvl[level];
@@ -1424,6 +1543,7 @@ extern "C" cuddle_status cuddle_scan_batch(cuddle_index *idx, const float *queri
     ST_TRY(use_device(idx->device));
     if (dim != idx->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, idx->dev.dim);
     if (n_queries == 0) return CUDDLE_OK;
+    ST_TRY(enter_stream(idx, nullptr));
     Plan pl;
     ST_TRY(make_plan(idx, n_queries, 1, 1, 1, max_u32(leaf_count, n_queries), pl));
     HostIO io;
@@ -1475,6 +1595,7 @@ extern "C" cuddle_status cuddle_search_leaves_batch(cuddle_index *idx, const flo
     uint64_t rerank_k;
     ST_TRY(rerank_k_of(k, rerank_factor, flags, rerank_k));
     if (n_queries == 0) return CUDDLE_OK;
+    ST_TRY(enter_stream(idx, nullptr));
     Plan pl;
     ST_TRY(make_plan(idx, n_queries, k, 1, rerank_k, max_u32(leaf_count, n_queries), pl));
     const bool want_sel = sel_pos && sel_key && sel_count;
@@ -1567,10 +1688,11 @@ extern "C" cuddle_status cuddle_route_batch_device(cuddle_index *idx, const floa
     hipStream_t s = static_cast<hipStream_t>(stream);
     idx->shard_state = 0;
     idx->timed = (flags & CUDDLE_SEARCH_TIME_STAGES) != 0 && idx->events_used + 4096 < kMaxEvents;
-    idx->last_stream = s;
+    ST_TRY(enter_stream(idx, s));
     Plan &pl = idx->shard_plan; // held by the handle: the copies below are asynchronous
     pl = Plan();
     ST_TRY(make_plan(idx, n_queries, 1, probes_per_level, 1, 0, pl));
+    if (pl.qc < n_queries) return fail(CUDDLE_ERR_UNSUPPORTED, "%u queries do not fit the work-space budget in one chunk (%u do)", n_queries, pl.qc);
     mark(idx, s, CUDDLE_STAGE_ROUTE);
     ST_TRY(launch_route(idx, pl, d_queries, n_queries, flags, s));
     HIP_TRY(hipMemcpy2DAsync(d_leaves, (size_t)leaf_stride * 4, pl.leaves, (size_t)pl.lstride * 4, (size_t)pl.lstride * 4, n_queries,
@@ -1596,12 +1718,13 @@ static cuddle_status shard_scan_impl(cuddle_index *idx, const float *d_queries, 
     ST_TRY(rerank_k_of(k, rerank_factor, flags, rerank_k));
     hipStream_t s = static_cast<hipStream_t>(stream);
     idx->timed = (flags & CUDDLE_SEARCH_TIME_STAGES) != 0 && idx->events_used + 4096 < kMaxEvents;
-    idx->last_stream = s;
+    ST_TRY(enter_stream(idx, s));
     idx->last_levels = idx->n_levels;
     HIP_TRY(hipMemsetAsync(idx->d_stats, 0, sizeof(DevStats), s));
     Plan &pl = idx->shard_plan;
     pl = Plan();
     ST_TRY(make_plan(idx, n_queries, k, probes_per_level, rerank_k, 0, pl));
+    if (pl.qc < n_queries) return fail(CUDDLE_ERR_UNSUPPORTED, "%u queries do not fit the work-space budget in one chunk (%u do)", n_queries, pl.qc);
     if (idx->timed) idx->timed_searches++;
     mark(idx, s, CUDDLE_STAGE_QUANTIZE);
     ST_TRY(launch_quantize(idx, pl, d_queries, n_queries, s));
@@ -1647,6 +1770,7 @@ extern "C" cuddle_status cuddle_shard_ties(cuddle_index *idx, const uint32_t *d_
     const Plan &pl = idx->shard_plan;
     const IndexDev &v = idx->dev;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    ST_TRY(enter_stream(idx, s));
     const size_t lds = scan_lds_bytes(v.dim, v.words, pl.lstride, 0, 0);
     mark(idx, s, CUDDLE_STAGE_SCAN); // the selection steps count as scan time
     if (v.dim < 255)
@@ -1673,6 +1797,7 @@ extern "C" cuddle_status cuddle_shard_finish(cuddle_index *idx, const float *d_q
     const IndexDev &v = idx->dev;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t nq = idx->shard_nq;
+    ST_TRY(enter_stream(idx, s));
     const size_t lds = scan_lds_bytes(v.dim, v.words, pl.lstride, 0, 0);
     mark(idx, s, CUDDLE_STAGE_SCAN);
     if (v.dim < 255)
@@ -1786,3 +1911,5 @@ extern "C" cuddle_status cuddle_merge_topk(const uint64_t *lists_ids, const floa
     }
     return CUDDLE_OK;
 }
+
+#include "cuddle_comm.hpp"

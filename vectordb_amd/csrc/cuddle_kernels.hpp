@@ -762,7 +762,7 @@ __device__ __forceinline__ uint32_t leaf_hamming(const uint4 *planes, uint32_t n
 struct ScanLds {
     uint32_t *hist;     // [dim + 2]
     uint32_t *lbeg;     // [lcap]      first leaf-contiguous position of each leaf slot
-    uint32_t *lcode;    // [lcap]      16-byte unit offset of the leaf's planar codes
+    uint32_t *lcode;    // [lcap + 1]  16-byte unit offset of the leaf's planar codes (one spare: reused for prefix sums)
     uint32_t *lscan;    // [lcap + 1]  exclusive prefix of leaf sizes = scan position of the leaf
     uint32_t *ltile;    // [lcap + 1]  exclusive prefix of the leaves' 64-vector tile counts
     uint32_t *tiles;    // [tcap]      (leaf slot << 12) | tile number inside the leaf
@@ -782,7 +782,7 @@ __device__ __forceinline__ ScanLds scan_lds_carve(unsigned char *smem, uint32_t 
     uint32_t *p = reinterpret_cast<uint32_t *>(smem);
     s.hist = p; p += scan_pad4(dim + 2);
     s.lbeg = p; p += scan_pad4(lcap);
-    s.lcode = p; p += scan_pad4(lcap);
+    s.lcode = p; p += scan_pad4(lcap + 1);
     s.lscan = p; p += scan_pad4(lcap + 1);
     s.ltile = p; p += scan_pad4(lcap + 1);
     s.tiles = p; p += scan_pad4(tcap);
@@ -797,7 +797,7 @@ __device__ __forceinline__ ScanLds scan_lds_carve(unsigned char *smem, uint32_t 
 
 inline size_t scan_lds_bytes(uint32_t dim, uint32_t words, uint32_t lcap, uint32_t tcap, uint32_t dist_cap,
                              bool with_tcode = false) {
-    size_t u32s = scan_pad4(dim + 2) + 2 * (size_t)scan_pad4(lcap) + 2 * (size_t)scan_pad4(lcap + 1) +
+    size_t u32s = scan_pad4(dim + 2) + (size_t)scan_pad4(lcap) + 3 * (size_t)scan_pad4(lcap + 1) +
                   (with_tcode ? 3 : 2) * (size_t)scan_pad4(tcap) + 32 +
                   8 + 2 * (size_t)((words + 1) & ~1u);
     return u32s * 4 + (size_t)dist_cap * 2;

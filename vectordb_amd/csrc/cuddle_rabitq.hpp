@@ -244,26 +244,32 @@ scan_all_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_all,
 
 // Reorders a query's selection (scan order) into phase-1 order (key, scan order) in place, so the
 // final top-k can break distance ties by position in the selection. One block per query;
-// dynamic LDS = next_pow2(max selection) * 16 bytes.
+// dynamic LDS = next_pow2(max selection) * 8 bytes (the sort keys only: 128 KiB at the largest
+// selection of 16384); the (position, key) pairs are permuted through the query's row of `pairs`
+// ([nq][sel_stride] u64 of global scratch), since a gather in place would overwrite its own sources.
 __global__ void __launch_bounds__(256)
-selection_sort_f32_kernel(uint32_t *sel_pos, uint32_t *sel_key, uint32_t sel_stride, const uint32_t *sel_count) {
+selection_sort_f32_kernel(uint32_t *sel_pos, uint32_t *sel_key, uint32_t sel_stride, const uint32_t *sel_count,
+                          uint64_t *pairs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
-    const uint32_t n = sel_count[q];
+    const uint32_t n = min(sel_count[q], sel_stride);
     const uint32_t npad = next_pow2(max(n, 1u));
     uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);
-    uint32_t *tpos = reinterpret_cast<uint32_t *>(skeys + npad), *tkey = tpos + npad;
     uint32_t *sp = sel_pos + (uint64_t)q * sel_stride, *sk = sel_key + (uint64_t)q * sel_stride;
-    for (uint32_t i = tid; i < npad; i += blockDim.x) {
+    uint64_t *pr = pairs + (uint64_t)q * sel_stride;
+    for (uint32_t i = tid; i < npad; i += blockDim.x)
         skeys[i] = i < n ? (((uint64_t)f32_key(__uint_as_float(sk[i])) << 32) | i) : ~0ull;
-        if (i < n) { tpos[i] = sp[i]; tkey[i] = sk[i]; }
-    }
     __syncthreads();
     block_bitonic_sort_u64(skeys, npad);
     for (uint32_t i = tid; i < n; i += blockDim.x) {
-        uint32_t j = (uint32_t)skeys[i];
-        sp[i] = tpos[j];
-        sk[i] = tkey[j];
+        const uint32_t j = (uint32_t)skeys[i];
+        pr[i] = ((uint64_t)sk[j] << 32) | sp[j];
+    }
+    __syncthreads(); // every source has been read before the first destination is written
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+        const uint64_t v = pr[i]; // written by this same thread above
+        sp[i] = (uint32_t)v;
+        sk[i] = (uint32_t)(v >> 32);
     }
 }
 

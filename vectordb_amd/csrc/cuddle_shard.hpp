@@ -96,7 +96,7 @@ shard_select_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const
     wave0_exclusive_scan_lds(s.ltile, nl);
     __syncthreads();
     const DistT *dist = reinterpret_cast<const DistT *>(gdist_v) + (uint64_t)q * gdist_stride;
-    uint32_t *sel_off = s.lcode; // codes are not read here: the slot's first output rank
+    uint32_t *sel_off = s.lcode; // [lcap + 1]; codes are not read here: the slot's first output rank, total at [nl]
     auto quota_of = [&](uint32_t sl) -> uint32_t { // how many of the slot's ties are inside the budget
         const uint32_t before = s.ltile[sl], ties = s.ltile[sl + 1] - before;
         return before >= budget ? 0u : min(ties, budget - before);

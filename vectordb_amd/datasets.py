@@ -110,8 +110,9 @@ def synthetic_mixture(n: int, dim: int, seed: int, device="cpu", n_top: int = 10
     return base, queries
 
 
-def brute_force_topk(base, queries, k: int, metric: str = "l2", chunk: int = 1 << 18):
-    """Exact ground truth on the GPU (torch): ids [nq,k] of the k nearest base rows."""
+def brute_force_topk(base, queries, k: int, metric: str = "l2", chunk: int = 1 << 18, return_dist: bool = False):
+    """Exact ground truth on the GPU (torch): row numbers [nq,k] of the k nearest base rows
+    (and their distances with return_dist, for merging the lists of several shards)."""
     import torch
 
     nq = queries.shape[0]
@@ -131,7 +132,7 @@ def brute_force_topk(base, queries, k: int, metric: str = "l2", chunk: int = 1 <
         ci = torch.cat([best_i, torch.arange(s, s + b.shape[0], device=b.device)[None, :].expand(nq, -1)], dim=1)
         best_d, sel = torch.topk(cd, k, dim=1, largest=False)
         best_i = torch.gather(ci, 1, sel)
-    return best_i
+    return (best_i, best_d) if return_dist else best_i
 
 
 def recall_at_k(found_ids: np.ndarray, gt_ids: np.ndarray, k: int) -> float:

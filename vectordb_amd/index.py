@@ -22,15 +22,15 @@ UINT64_MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 @dataclass
 class SearchStats:
-    """SearchStats (hierarchical.rs:36-45); batch calls sum over the queries."""
+    """SearchStats (hierarchical.rs:36-45), one per query, field for field."""
     total_leaves: int
     leaves_searched: int
+    leaves_searched_ids: List[int]   # accumulation order (hierarchical.rs:902, :917)
     total_vectors: int
     vectors_scanned_binary: int
     vectors_reranked_full: int
-    tree_depth: int
-    max_candidates: int = 0
-    max_leaves: int = 0
+    tree_depth: int                  # depth of the deepest node (the reference's max_depth, :851)
+    probes_per_level: List[int]      # frontier size at every level, ending with the empty frontier (:861)
 
 
 class DeviceIndex:
@@ -112,6 +112,27 @@ class DeviceIndex:
             C.c_void_p(out_ids.data_ptr()), C.c_void_p(out_dist.data_ptr()), C.c_void_p(out_count.data_ptr()),
             C.c_void_p(stream)))
         return out_ids, out_dist, out_count
+
+    def search_batch_with_stats(self, queries: np.ndarray, k: int, probes: int, rerank_factor: int):
+        """search_with_stats (hierarchical.rs:831-938) for every row of `queries`: (ids, dist, count,
+        leaves [nq, leaf_stride], leaf_count, level_nodes [nq, levels + 1], level_count, scanned, reranked)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        nq, dim = q.shape
+        ids = np.empty((nq, k), dtype=np.uint64)
+        dist = np.empty((nq, k), dtype=np.float32)
+        count = np.zeros(nq, dtype=np.uint32)
+        lstride = self.leaf_stride(probes)
+        leaves = np.zeros((nq, lstride), dtype=np.uint32)
+        lcount = np.zeros(nq, dtype=np.uint32)
+        level_nodes = np.zeros((nq, self.levels + 1), dtype=np.uint32)
+        level_count = np.zeros(nq, dtype=np.uint32)
+        scanned = np.zeros(nq, dtype=np.uint32)
+        reranked = np.zeros(nq, dtype=np.uint32)
+        _ffi.check(self._lib.cuddle_search_batch_with_stats(
+            self._handle, _ffi.ptr(q), nq, dim, k, probes, rerank_factor, _ffi.ptr(ids), _ffi.ptr(dist), _ffi.ptr(count),
+            _ffi.ptr(leaves), lstride, _ffi.ptr(lcount), _ffi.ptr(level_nodes), self.levels + 1, _ffi.ptr(level_count),
+            _ffi.ptr(scanned), _ffi.ptr(reranked)))
+        return ids, dist, count, leaves, lcount, level_nodes, level_count, scanned, reranked
 
     # ---- leaf-sharded exact search: the three steps between which the shards exchange counts ----
     def shard_scan(self, d_queries, k: int, probes_per_level: int, rerank_factor: int, flags: int = 0,
@@ -236,7 +257,7 @@ class DeviceIndex:
     def route_batch(self, queries: np.ndarray, probes_per_level: int, flags: int = 0):
         q = np.ascontiguousarray(queries, dtype=np.float32)
         nq, dim = q.shape
-        stride = max(1, min(probes_per_level, self.flat.n_nodes) * max(self.levels, 1))
+        stride = max(1, self.leaf_stride(probes_per_level))
         leaves = np.zeros((nq, stride), dtype=np.uint32)
         count = np.zeros(nq, dtype=np.uint32)
         _ffi.check(self._lib.cuddle_route_batch(self._handle, _ffi.ptr(q), nq, dim, probes_per_level, flags,
@@ -330,13 +351,23 @@ class ClusteredIndex:
     def search_with_stats(self, query: Sequence[float], k: int, probes: int, rerank_factor: int):
         """search_with_stats (hierarchical.rs:831-938)."""
         q = np.asarray(query, dtype=np.float32).reshape(1, -1)
-        ids, dist, count, st = self.dev.search_batch(q, k, probes, rerank_factor, _ffi.SEARCH_STATS_VARIANT, want_stats=True)
-        stats = SearchStats(
-            total_leaves=int(self.flat.is_leaf().sum()), leaves_searched=st["leaves_searched"],
-            total_vectors=self.flat.n_vectors, vectors_scanned_binary=st["vectors_scanned"],
-            vectors_reranked_full=st["vectors_reranked"], tree_depth=max(self.dev.levels - 1, 0),
-            max_candidates=st["max_candidates"], max_leaves=st["max_leaves"])
-        return [(int(ids[0, i]), float(dist[0, i])) for i in range(int(count[0]))], stats
+        results, stats = self.search_batch_with_stats(q, k, probes, rerank_factor)
+        return results[0], stats[0]
+
+    def search_batch_with_stats(self, queries: np.ndarray, k: int, probes: int, rerank_factor: int):
+        """search_with_stats for every row: ([results per query], [SearchStats per query])."""
+        ids, dist, count, leaves, lcount, lvl, lvlc, scanned, reranked = self.dev.search_batch_with_stats(
+            queries, k, probes, rerank_factor)
+        total_leaves = int(self.flat.is_leaf().sum())
+        results, stats = [], []
+        for i in range(ids.shape[0]):
+            results.append([(int(ids[i, j]), float(dist[i, j])) for j in range(int(count[i]))])
+            stats.append(SearchStats(
+                total_leaves=total_leaves, leaves_searched=int(lcount[i]),
+                leaves_searched_ids=[int(v) for v in leaves[i, :lcount[i]]], total_vectors=self.flat.n_vectors,
+                vectors_scanned_binary=int(scanned[i]), vectors_reranked_full=int(reranked[i]),
+                tree_depth=max(self.dev.levels - 1, 0), probes_per_level=[int(v) for v in lvl[i, :lvlc[i]]]))
+        return results, stats
 
     def len(self) -> int:
         return len(self)

@@ -265,3 +265,57 @@ def exact_search_in_process(engines, queries: torch.Tensor, k: int, probes_per_l
     all_dist = torch.stack([o[1] for o in outs])
     all_order = torch.stack([o[2] for o in outs])
     return merge_gathered_ordered(all_ids, all_dist, all_order, k)
+
+
+class RcclShardedSearcher:
+    """The exact sharded search with the collectives inside the library (cuddle_comm_* /
+    cuddle_sharded_search_batch: RCCL called from C, no torch.distributed on the data path).
+    `unique_id` comes from `RcclShardedSearcher.make_unique_id()` on rank 0 and reaches the other
+    ranks through any channel the host has (here typically torch.distributed's store)."""
+
+    def __init__(self, dev_index, rank: int, world: int, unique_id: bytes):
+        import ctypes as C
+
+        from . import _ffi
+        self._ffi, self._C = _ffi, C
+        self.dev = dev_index
+        self.rank, self.world = rank, world
+        self._comm = C.c_void_p(None)
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _ffi.check(_ffi.lib().cuddle_comm_init(rank, world, C.cast(buf, C.c_void_p), dev_index.device_id, C.byref(self._comm)))
+
+    @staticmethod
+    def make_unique_id() -> bytes:
+        import ctypes as C
+
+        from . import _ffi
+        buf = (C.c_uint8 * 128)()
+        _ffi.check(_ffi.lib().cuddle_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def close(self) -> None:
+        if self._comm is not None and self._comm.value:
+            self._ffi.lib().cuddle_comm_destroy(self._comm)
+            self._comm = self._C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search_batch(self, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int, flags: int = 0,
+                     out_ids=None, out_dist=None, out_count=None):
+        C = self._C
+        assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
+        nq, dim = queries.shape
+        dev = queries.device
+        ids = out_ids if out_ids is not None else torch.empty((nq, k), dtype=torch.int64, device=dev)
+        dd = out_dist if out_dist is not None else torch.empty((nq, k), dtype=torch.float32, device=dev)
+        cnt = out_count if out_count is not None else torch.empty((nq,), dtype=torch.int32, device=dev)
+        self._ffi.check(self._ffi.lib().cuddle_sharded_search_batch(
+            self.dev._handle, self._comm, C.c_void_p(queries.data_ptr()), nq, dim, k, probes_per_level, rerank_factor, flags,
+            C.c_void_p(ids.data_ptr()), C.c_void_p(dd.data_ptr()), C.c_void_p(cnt.data_ptr()),
+            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return ids, dd, cnt

@@ -123,41 +123,70 @@ def _rabitq_encode_device(vectors: torch.Tensor, rot_t: torch.Tensor, chunk: int
 
 def build_tree_index_on_device(dim: int, fanout: int, levels: int, leaf_size: int, device, seed: int = 0,
                                sigmas=(0.35, 0.22, 0.12), metric: int = _ffi.METRIC_L2, style: str = "sift",
-                               n_queries: int = 0, chunk_leaves: int = 8192, code_kind: int = _ffi.CODE_BINARY):
-    """Returns (DeviceTreeIndex, queries [n_queries, dim]). N = fanout**levels * leaf_size vectors.
+                               n_queries: int = 0, chunk_leaves: int = 8192, code_kind: int = _ffi.CODE_BINARY,
+                               rank: int = 0, world: int = 1, group=None):
+    """Returns (DeviceTreeIndex, queries [n_queries, dim]).
     sigmas: spread of each level's centres around its parent, last entry = spread of the points
-    around their leaf centre. style "sift": values mapped to non-negative integers in the u8 range."""
-    assert levels >= 1 and len(sigmas) >= 2
+    around their leaf centre. style "sift": values mapped to non-negative integers in the u8 range.
+
+    world == 1: the whole index, N = fanout**levels * leaf_size vectors.
+    world > 1 (one process per GPU, torch.distributed initialised): the index has `world` times as
+    many first-level nodes (N = world * fanout**levels * leaf_size) and this call returns leaf shard
+    `rank` of it: the whole tree with every centroid (every rank must route identically), and the
+    vectors, codes and ids of the leaves j with j % world == rank only, generated here and nowhere
+    else. The ranks exchange what the tree needs - each leaf's centroid (an all-gather) and the sum
+    of all values for the binary threshold (an all-reduce); queries are the same on every rank."""
+    assert levels >= 1 and len(sigmas) >= 2 and 0 <= rank < world
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    widths = [fanout ** (l + 1) for l in range(levels)]
+    widths = [world * fanout ** (l + 1) for l in range(levels)]
     offs = np.concatenate([[0], np.cumsum(widths)]).astype(np.int64)
     n_nodes, n_leaves = int(offs[-1]), widths[-1]
-    n_vec = n_leaves * leaf_size
-    # generating centres, level by level
+    # generating centres, level by level (the same on every rank)
     centres = [torch.rand((widths[0], dim), generator=g, device=device) * 2 - 1]
     for l in range(1, levels):
         s = sigmas[min(l - 1, len(sigmas) - 2)]
         parent = centres[-1].repeat_interleave(fanout, dim=0)
         centres.append(parent + s * torch.randn((widths[l], dim), generator=g, device=device))
     sig_pts = sigmas[-1]
+    # the points of a rank come from a stream of their own, so that the shared stream stays in step
+    gp = g
+    if world > 1:
+        gp = torch.Generator(device=device)
+        gp.manual_seed(seed + 7919 * (rank + 1))
 
     def finish(x):
         if style == "sift":
             return torch.clamp(torch.round((x + 1.8) * 50.0), 0, 255)
         return x
 
+    own = torch.arange(rank, n_leaves, world, device=device)  # this rank's leaves, ascending node order
+    n_own = int(own.shape[0])
+    n_vec = n_own * leaf_size
     vectors = torch.empty((n_vec, dim), dtype=torch.float32, device=device)
-    leaf_cent = torch.empty((n_leaves, dim), dtype=torch.float32, device=device)
+    own_cent = torch.empty((n_own, dim), dtype=torch.float32, device=device)
     total = torch.zeros((), dtype=torch.float64, device=device)
-    for a in range(0, n_leaves, chunk_leaves):
-        b = min(a + chunk_leaves, n_leaves)
-        x = centres[-1][a:b, None, :] + sig_pts * torch.randn((b - a, leaf_size, dim), generator=g, device=device)
+    for a in range(0, n_own, chunk_leaves):
+        b = min(a + chunk_leaves, n_own)
+        x = centres[-1][own[a:b], None, :] + sig_pts * torch.randn((b - a, leaf_size, dim), generator=gp, device=device)
         x = finish(x)
-        leaf_cent[a:b] = x.mean(dim=1)
+        own_cent[a:b] = x.mean(dim=1)
         total += x.double().sum()
         vectors[a * leaf_size:b * leaf_size] = x.reshape(-1, dim)
-    threshold = float((total / (n_vec * dim)).item())
+    if world > 1:
+        import torch.distributed as dist
+        # RCCL works on the device buffers; a gloo rehearsal (several ranks on one GPU) goes through the host
+        where = "cpu" if dist.get_backend(group) == "gloo" else device
+        gathered = torch.empty((world, n_own, dim), dtype=torch.float32, device=where)
+        dist.all_gather_into_tensor(gathered.view(world * n_own, dim), own_cent.to(where), group=group)
+        leaf_cent = gathered.to(device).permute(1, 0, 2).reshape(n_leaves, dim).contiguous()  # leaf j = i * world + r
+        del gathered
+        total_h = total.to(where)
+        dist.all_reduce(total_h, group=group)
+        total = total_h.to(device)
+    else:
+        leaf_cent = own_cent
+    threshold = float((total / (n_leaves * leaf_size * dim)).item())
     codes, rq = None, {}
     if code_kind == _ffi.CODE_BINARY:
         codes = torch.empty((n_vec, (dim + 63) // 64), dtype=torch.int64, device=device)
@@ -175,6 +204,7 @@ def build_tree_index_on_device(dim: int, fanout: int, levels: int, leaf_size: in
     for l in range(levels - 2, -1, -1):
         cents[l] = cents[l + 1].view(widths[l], fanout, dim).mean(dim=1)
     centroids = torch.cat(cents, dim=0).contiguous()
+    del cents, leaf_cent
     # tree arrays (host)
     child_offsets = np.zeros(n_nodes + 1, dtype=np.uint32)
     counts = np.zeros(n_nodes, dtype=np.int64)
@@ -182,11 +212,12 @@ def build_tree_index_on_device(dim: int, fanout: int, levels: int, leaf_size: in
     child_offsets[1:] = np.cumsum(counts)
     children = np.arange(offs[1], n_nodes, dtype=np.uint32) if levels > 1 else np.zeros(0, dtype=np.uint32)
     vec_counts = np.zeros(n_nodes, dtype=np.int64)
-    vec_counts[offs[levels - 1]:] = leaf_size
+    vec_counts[offs[levels - 1] + rank::world] = leaf_size
     vec_offsets = np.zeros(n_nodes + 1, dtype=np.uint64)
     vec_offsets[1:] = np.cumsum(vec_counts)
     roots = np.arange(widths[0], dtype=np.uint32)
-    ids = torch.arange(n_vec, dtype=torch.int64, device=device)
+    # id of a vector = its place in the whole index: leaf * leaf_size + place in the leaf
+    ids = (own[:, None] * leaf_size + torch.arange(leaf_size, device=device)[None, :]).reshape(-1).to(torch.int64)
     queries = torch.empty((0, dim), device=device)
     if n_queries:
         leaf = torch.randint(0, n_leaves, (n_queries,), generator=g, device=device)
