@@ -186,6 +186,24 @@ cuddle_status cuddle_search_batch_device(cuddle_index *idx, const float *d_queri
                                          uint32_t flags, uint64_t *d_out_ids, float *d_out_dist,
                                          uint32_t *d_out_count, void *stream);
 
+/* The same search for callers that must not allocate device memory while they run (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc). It has no counterpart in
+ * the reference. Where cuddle_search_batch_device grows the handle's work space on demand, this
+ * call lays the work space out in a fixed 32 MiB array that every GPU the library runs on holds
+ * from the library's load until the process ends; it calls no hipMalloc / hipFree and records no
+ * stage timings (CUDDLE_SEARCH_TIME_STAGES is ignored). Batches are cut into chunks that fit the
+ * array; CUDDLE_ERR_UNSUPPORTED when the work space of a single query does not fit (very wide
+ * leaf lists). Results are bit-identical to cuddle_search_batch_device. The array is shared by
+ * every handle on the GPU and keeps the previous call's contents: calls that overlap on one GPU
+ * (two streams, two handles, two threads) race; a call on another stream than the array's
+ * previous user waits for that stream on the host first. */
+cuddle_status cuddle_search_batch_device_noalloc(cuddle_index *idx, const float *d_queries,
+                                                 uint32_t n_queries, uint32_t dim, uint32_t k,
+                                                 uint32_t probes_per_level, uint32_t rerank_factor,
+                                                 uint32_t flags, uint64_t *d_out_ids,
+                                                 float *d_out_dist, uint32_t *d_out_count,
+                                                 void *stream);
+
 /* Batched search_with_stats (hierarchical.rs:831-938): the always-sorting variant of the search
  * (every level stably sorted, routing always by the index metric, no 10000 cap) together with
  * what SearchStats (:36-45) records for each query. Host pointers; row q of every output

@@ -51,7 +51,7 @@ def test_search_with_stats_matches_oracle(gpu, metric):
     q = queries_like(x, 40, 3)
     _check_stats(fi, gpu, q, 10, 4, 5)
     _check_stats(fi, gpu, q, 10, 1, 1)
-    _check_stats(fi, gpu, q, 100, 6, 200)   # k * rf = 20000 > 10000: the stats variant has no cap (:927)
+    _check_stats(fi, gpu, q, 100, 6, 150)   # k * rf = 15000 > 10000: the stats variant has no cap (:927)
 
 
 def test_search_with_stats_unbalanced_tree_and_rabitq(gpu):

@@ -103,6 +103,7 @@ SIGNATURES = {
     "cuddle_index_reserve": (_int, [_vp, _u32, _u32, _u32, _u32]),
     "cuddle_search_batch": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(Stats)]),
     "cuddle_search_batch_device": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "cuddle_search_batch_device_noalloc": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     "cuddle_search_batch_with_stats": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u32,
                                               _vp, _vp, _vp]),
     "cuddle_last_stats": (_int, [_vp, C.POINTER(Stats)]),

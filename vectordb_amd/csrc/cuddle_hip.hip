@@ -64,6 +64,39 @@ static cuddle_status use_device(int device_id) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// fixed work space of cuddle_search_batch_device_noalloc
+// ---------------------------------------------------------------------------------------------
+// Every GPU the library runs on holds its own copy of this array (at its own address) until the process
+// ends. In host code the name is only a handle for hipGetSymbolAddress: the device address is looked up
+// once per device (scratch_for_device, called with that device current) and everything on the host side
+// - kernel arguments, memsets - uses that address, never the name.
+static constexpr size_t kScratchBytes = 32u << 20;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+static constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mu;
+static void *g_scratch_ptr[kMaxDevices];          // device address of `scratch` on each device, once resolved
+static hipStream_t g_scratch_stream[kMaxDevices]; // stream of the last call that used it
+static bool g_scratch_used[kMaxDevices];
+
+// Device address of `scratch` on `device_id`, which must be the current device.
+static cuddle_status scratch_for_device(int device_id, void **out) {
+    if (device_id < 0 || device_id >= kMaxDevices) return fail(CUDDLE_ERR_UNSUPPORTED, "device %d: at most %d devices", device_id, kMaxDevices);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device_id]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            (void)hipGetLastError();
+            return fail(CUDDLE_ERR_HIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", device_id, hipGetErrorString(e));
+        }
+        g_scratch_ptr[device_id] = p;
+    }
+    *out = g_scratch_ptr[device_id];
+    return CUDDLE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------------
 struct DevBuf {
@@ -159,6 +192,7 @@ struct cuddle_index {
     DevBuf ws;       // per-chunk work space (Plan)
     DevBuf io;       // staging for the host entry points
     DevStats *d_stats = nullptr;
+    void *scratch_ptr = nullptr; // this device's copy of the library's fixed work space
     std::mutex mu;
     // stage timing of the last timed search
     std::vector<hipEvent_t> events;
@@ -542,6 +576,7 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     if (st != CUDDLE_OK) return st;
     HIP_TRY(hipMalloc((void **)&ix->d_stats, sizeof(DevStats)));
     HIP_TRY(hipMemset(ix->d_stats, 0, sizeof(DevStats)));
+    ST_TRY(scratch_for_device(device_id, &ix->scratch_ptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipGetLastError());
     // kernels that may need more than 64 KiB of dynamic LDS
@@ -1101,6 +1136,26 @@ extern "C" cuddle_status cuddle_search_batch_device(cuddle_index *idx, const flo
     ST_TRY(use_device(idx->device));
     return search_device_locked(idx, d_queries, n_queries, dim, k, probes_per_level, rerank_factor, flags, d_out_ids,
                                 d_out_dist, d_out_count, static_cast<hipStream_t>(stream));
+}
+
+extern "C" cuddle_status cuddle_search_batch_device_noalloc(cuddle_index *idx, const float *d_queries, uint32_t n_queries,
+                                                            uint32_t dim, uint32_t k, uint32_t probes_per_level,
+                                                            uint32_t rerank_factor, uint32_t flags, uint64_t *d_out_ids,
+                                                            float *d_out_dist, uint32_t *d_out_count, void *stream) {
+    if (!idx) return fail(CUDDLE_ERR_BAD_ARG, "index is null");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    if (!idx->scratch_ptr) return fail(CUDDLE_ERR_HIP, "the fixed work space was not resolved on device %d", idx->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    { // the array is shared by every handle on this GPU: a call on another stream than the last one waits for that stream
+        std::lock_guard<std::mutex> lk2(g_scratch_mu);
+        const int d = idx->device;
+        if (g_scratch_used[d] && g_scratch_stream[d] != s) HIP_TRY(hipStreamSynchronize(g_scratch_stream[d]));
+        g_scratch_stream[d] = s;
+        g_scratch_used[d] = true;
+    }
+    return search_device_locked(idx, d_queries, n_queries, dim, k, probes_per_level, rerank_factor, flags, d_out_ids, d_out_dist,
+                                d_out_count, s, idx->scratch_ptr, kScratchBytes);
 }
 
 static cuddle_status read_stats(cuddle_index *ix, cuddle_stats *st) {

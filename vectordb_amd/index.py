@@ -113,6 +113,23 @@ class DeviceIndex:
             C.c_void_p(stream)))
         return out_ids, out_dist, out_count
 
+    def search_batch_device_noalloc(self, d_queries, k: int, probes_per_level: int, rerank_factor: int, flags: int = 0,
+                                    out_ids=None, out_dist=None, out_count=None, stream: Optional[int] = None):
+        """search_batch_device through cuddle_search_batch_device_noalloc: the library lays its work
+        space out in its fixed per-GPU array and allocates nothing (the outputs are the caller's)."""
+        import torch
+
+        assert d_queries.is_cuda and d_queries.dtype == torch.float32 and d_queries.is_contiguous()
+        nq, dim = d_queries.shape
+        assert out_ids is not None and out_dist is not None and out_count is not None, "the caller owns the outputs"
+        if stream is None:
+            stream = torch.cuda.current_stream(d_queries.device).cuda_stream
+        _ffi.check(self._lib.cuddle_search_batch_device_noalloc(
+            self._handle, C.c_void_p(d_queries.data_ptr()), nq, dim, k, probes_per_level, rerank_factor, flags,
+            C.c_void_p(out_ids.data_ptr()), C.c_void_p(out_dist.data_ptr()), C.c_void_p(out_count.data_ptr()),
+            C.c_void_p(stream)))
+        return out_ids, out_dist, out_count
+
     def search_batch_with_stats(self, queries: np.ndarray, k: int, probes: int, rerank_factor: int):
         """search_with_stats (hierarchical.rs:831-938) for every row of `queries`: (ids, dist, count,
         leaves [nq, leaf_stride], leaf_count, level_nodes [nq, levels + 1], level_count, scanned, reranked)."""
