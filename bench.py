@@ -123,7 +123,8 @@ def spawn_ranks(n: int) -> int:
                     procs[o].terminate()
         time.sleep(0.05)
     out0.seek(0)
-    sys.stdout.write(out0.read())
+    for line in out0:  # rank 0's result line; anything else a library printed on stdout goes to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
     sys.stdout.flush()
     return rc
 
@@ -446,7 +447,8 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
                     note=("the whole code array fits the 256 MiB Infinity Cache: achieved is on-die cache bandwidth as much as "
                           "HBM bandwidth (see roofline_hbm_resident for the same kernel on a code array that does not fit); "
                           if fits_l3 else "the code array is larger than the 256 MiB Infinity Cache: the scan streams from HBM; ") +
-                         f"achieved = algorithmic code bytes per second; the timed loop rotates {N_BATCHES} query batches")
+                         f"achieved = algorithmic code bytes / mean duration of the scan kernel alone (HIP events around that launch; "
+                         f"the candidate-count / block-order kernel before it is stage scan_prep); the timed loop rotates {N_BATCHES} query batches")
     del dev_index_codes_bytes
 
     # routing filter: approximate (matrix-core) distances against the error bound its proof uses

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CUDDLE_ABI_VERSION 1
+#define CUDDLE_ABI_VERSION 2
 
 typedef enum cuddle_status {
     CUDDLE_OK = 0,
@@ -140,10 +140,11 @@ typedef struct cuddle_stats {
 enum {
     CUDDLE_STAGE_QUANTIZE = 0, /* R1   query binarisation / RaBitQ query prep */
     CUDDLE_STAGE_ROUTE = 1,    /* R2+R3 all tree levels */
-    CUDDLE_STAGE_SCAN = 2,     /* R4+R5 leaf scan + phase-1 selection */
+    CUDDLE_STAGE_SCAN = 2,     /* R4+R5 the leaf scan + phase-1 selection kernel(s) */
     CUDDLE_STAGE_RERANK = 3,   /* R6 */
     CUDDLE_STAGE_TOPK = 4,     /* R7 */
-    CUDDLE_STAGE_COUNT = 5
+    CUDDLE_STAGE_SCAN_PREP = 5, /* candidate counts per query and the order in which the scan takes the queries */
+    CUDDLE_STAGE_COUNT = 6
 };
 
 /* ---- library ---------------------------------------------------------------------------- */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CUDDLE_HIP_LIB selects another build of the same library (kernel tuning experiments).
 LIB_PATH = os.environ.get("CUDDLE_HIP_LIB") or os.path.join(_HERE, "libcuddle_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, ERR_BAD_ARG, ERR_BAD_DIM, ERR_HIP, ERR_NO_DEVICE, ERR_OOM, ERR_BAD_INDEX, ERR_UNSUPPORTED, ERR_RCCL = range(9)
 STATUS_NAMES = {
@@ -38,7 +38,7 @@ SEARCH_ROUTE_EXACT_ONLY = 0x4
 SEARCH_ROUTE_GROUPED = 0x8
 DESC_DEVICE_ARRAYS = 0x1
 DESC_ADOPT_VECTORS = 0x2
-STAGE_NAMES = ("quantize", "route", "scan", "rerank", "topk")
+STAGE_NAMES = ("quantize", "route", "scan", "rerank", "topk", "scan_prep")
 
 
 class CuddleError(RuntimeError):

@@ -247,6 +247,9 @@ static GroupedKernel grouped_kernel_for(uint32_t dim, uint32_t metric) {
     }
 }
 
+#ifndef CUDDLE_SCAN_U2
+#define CUDDLE_SCAN_U2 8 // tiles a wave keeps in flight when a code is one 16-byte slot (dim <= 128)
+#endif
 using ScanKernel = void (*)(IndexDev, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, uint32_t,
                             uint32_t, uint32_t, void *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *,
                             const uint32_t *, uint32_t *);
@@ -254,7 +257,7 @@ using ScanKernel = void (*)(IndexDev, const uint64_t *, const uint32_t *, uint32
 // The Hamming scan instantiation for a code of `words` u64 (distances in u8 when dim < 255).
 static ScanKernel scan_kernel_for(uint32_t dim, uint32_t words) {
     switch (words) {
-    case 2: return dim < 255 ? scan_select_hamming_kernel<uint8_t, 1, false, 16> : scan_select_hamming_kernel<uint16_t, 1, false, 16>;
+    case 2: return dim < 255 ? scan_select_hamming_kernel<uint8_t, 1, false, CUDDLE_SCAN_U2> : scan_select_hamming_kernel<uint16_t, 1, false, CUDDLE_SCAN_U2>;
     case 4: return dim < 255 ? scan_select_hamming_kernel<uint8_t, 2, false, 8> : scan_select_hamming_kernel<uint16_t, 2, false, 8>;
     case 8: return scan_select_hamming_kernel<uint16_t, 4, false, 4>;   // 512-d
     case 12: return scan_select_hamming_kernel<uint16_t, 6, false, 2>;  // 768-d
@@ -720,7 +723,8 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     pl.tcap = (uint32_t)align_up((size_t)pl.lstride + pl.cstride / 64 + 1, 4);
     // small per-query scans (few candidates): smaller blocks, more of them per CU, so that the
     // latency-bound prologue/selection phases of one query overlap the streaming of others
-    pl.scan_threads = pl.cstride <= 16384 ? 256 : kScanThreads;
+    // (two-word codes are built for 8 waves per SIMD: whole-CU occupancy with 512-thread blocks)
+    pl.scan_threads = (pl.cstride <= 16384 && v.words != 2) ? 256 : kScanThreads;
     if (const char *e = getenv("CUDDLE_SCAN_THREADS")) {  // tuning aid; the kernels are bounded at 512 threads
         const int t = atoi(e);
         if (t >= 64 && t <= (int)kScanThreads && t % 64 == 0) pl.scan_threads = (uint32_t)t;
@@ -1034,10 +1038,12 @@ extern "C" int cuddle_debug_stamps(uint64_t *out, uint32_t n_blocks) {
 static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32_t nq, hipStream_t s,
                                         uint32_t *ghist = nullptr) {
     const IndexDev &v = ix->dev;
-    // longest queries first (nq <= kMaxChunk = 4096 fits one sorting block)
+    // candidate counts and the block order, longest queries first (nq <= kMaxChunk = 4096)
+    mark(ix, s, CUDDLE_STAGE_SCAN_PREP);
     hipLaunchKernelGGL(cand_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, pl.leaves, pl.lstride, pl.lcount, nq,
                        pl.cand_count);
     hipLaunchKernelGGL(order_by_work_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, pl.cand_count, nq, pl.order);
+    mark(ix, s, CUDDLE_STAGE_SCAN);
     if (v.code_kind == CUDDLE_CODE_RABITQ) {
         const float *rq = reinterpret_cast<const float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
         hipLaunchKernelGGL(scan_select_rabitq_kernel, dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, rq, qn, pl.leaves,

@@ -966,11 +966,11 @@ order_by_work_kernel(const uint32_t *cand_count, uint32_t nq, uint32_t *order) {
 // sel_pos / sel_key: [nq][sel_stride]; gdist: [nq][gdist_stride] spill.
 // One instantiation per code width (PAIRS = 0: any width, generic loop) so that each gets its own
 // register allocation; gdist_v points at DistT elements.
-#ifndef CUDDLE_SCAN_WAVES
-#define CUDDLE_SCAN_WAVES 1
-#endif
+// Occupancy: with one 16-byte slot per code (PAIRS == 1, no tail) a block's time is mostly the latency of its
+// prologue and selection, so the kernel is built for 8 waves per SIMD (at most 64 registers); the wider codes
+// keep more loads in flight per wave instead and take the registers they need.
 template <class DistT, int PAIRS, bool TAIL, int U>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(CUDDLE_SCAN_WAVES)))
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((PAIRS == 1 && !TAIL) ? 8 : 1)))
 scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *leaves, uint32_t lstride,
                            const uint32_t *lcount, uint32_t lcap, uint32_t tcap, uint32_t rerank_k, uint32_t dist_cap,
                            void *gdist_v, uint32_t gdist_stride, uint32_t *sel_pos, uint32_t *sel_key,
