@@ -57,13 +57,15 @@ def main():
     fn.restype = ctypes.c_int
     out = np.zeros((16384, 8), dtype=np.uint64)
     assert fn(out.ctypes.data, 16384) == 0
-    t = out[:, :npts].astype(np.int64)
+    order = [int(c) for c in sys.argv[4].split(",")] if len(sys.argv) > 4 else list(range(npts))  # stamp numbers in program order
+    npts = len(order)
+    t = out[:, order].astype(np.int64)
     t = t[(t[:, 0] > 0) & (t[:, npts - 1] > 0)]
     for i in range(1, npts):  # a phase the block's path skipped (no stamp) counts as zero time
         t[:, i] = np.where(t[:, i] > 0, t[:, i], t[:, i - 1])
     d = np.diff(t, axis=1) * 0.01  # 100 MHz ticks -> microseconds
     for i in range(npts - 1):
-        print(f"stamp {i} -> {i + 1}: mean {d[:, i].mean():8.2f} us   p50 {np.median(d[:, i]):8.2f}   max {d[:, i].max():8.2f}")
+        print(f"stamp {order[i]} -> {order[i + 1]}: mean {d[:, i].mean():8.2f} us   p50 {np.median(d[:, i]):8.2f}   max {d[:, i].max():8.2f}")
     life = (t[:, -1] - t[:, 0]) * 0.01
     span = (t[:, -1].max() - t[:, 0].min()) * 0.01
     print(f"blocks {len(t)}; lifetime mean {life.mean():.2f} us; span {span:.1f} us; in flight (avg) {life.sum() / span:.1f}")

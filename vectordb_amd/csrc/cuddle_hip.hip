@@ -155,6 +155,7 @@ struct Plan {
     uint64_t *sel_ord = nullptr;
     float *qnorm = nullptr; // cosine: sqrt(dot(q, q)) per query
     uint32_t *level_fc = nullptr; // [n_levels + 1][qc] frontier size of every query at every level (stats variant)
+    uint32_t *leaf_tables = nullptr; // [qc][4][lstride + 4] per-slot tables of the reached leaves (cand_count_kernel)
     uint32_t *sel_pos = nullptr, *sel_key = nullptr, *sel_count = nullptr, *cand_count = nullptr;
     float *sel_dist = nullptr;
     // MFMA routing
@@ -162,7 +163,6 @@ struct Plan {
     float *qsq = nullptr, *rc_dist = nullptr, *rc_max = nullptr;
     uint16_t *qcent = nullptr; // centred queries as bf16 (hi, lo) pairs
     uint32_t *rc_pos = nullptr, *rflag = nullptr, *rc_cnt = nullptr;
-    uint32_t *order = nullptr; // queries by decreasing candidate count
     size_t bytes = 0;
 };
 
@@ -250,9 +250,8 @@ static GroupedKernel grouped_kernel_for(uint32_t dim, uint32_t metric) {
 #ifndef CUDDLE_SCAN_U2
 #define CUDDLE_SCAN_U2 8 // tiles a wave keeps in flight when a code is one 16-byte slot (dim <= 128)
 #endif
-using ScanKernel = void (*)(IndexDev, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, uint32_t,
-                            uint32_t, uint32_t, void *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *,
-                            const uint32_t *, uint32_t *);
+using ScanKernel = void (*)(IndexDev, const uint64_t *, const uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
+                            void *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *);
 
 // The Hamming scan instantiation for a code of `words` u64 (distances in u8 when dim < 255).
 static ScanKernel scan_kernel_for(uint32_t dim, uint32_t words) {
@@ -651,13 +650,13 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     size_t o_sc = carve(qc * 4), o_cc = carve(qc * 4);
     size_t o_qcent = carve(qc * split_kp(v.dim) * 4), o_qsq = carve(qc * 4);
     size_t o_rcp = carve(qc * pl.kc_cap * 4), o_rcd = carve(qc * pl.kc_cap * 4), o_rcm = carve(qc * 4), o_rfl = carve(qc * 4), o_rcc = carve(qc * 4);
-    size_t o_ord = carve(qc * 4);
     const size_t gw = (size_t)ix->max_parent_width + 1;
     size_t o_pi = carve(qc * pl.probes * 4), o_pp = carve(qc * pl.probes * 4), o_ps = carve(qc * pl.probes * 4), o_pl = carve(qc * pl.probes * 4);
     size_t o_sf = carve(qc * 4), o_gc = carve(gw * 4), o_gp = carve(gw * 4), o_gi = carve(gw * 4), o_gf = carve(gw * 4);
     size_t o_git = carve((qc * pl.probes / kGroupPairs + gw + 1) * 16);
     size_t o_thr = carve(qc * 8), o_sord = carve(qc * pl.sstride * 8), o_qn = carve(qc * 4);
     size_t o_lfc = carve(qc * ((size_t)ix->n_levels + 1) * 4);
+    size_t o_ltb = carve(qc * 4 * ((size_t)pl.lstride + 4) * 4);
     if (!b) return off;
     pl.qcodes = (uint64_t *)(b + o_qcodes);
     pl.frontier[0] = (uint32_t *)(b + o_f0); pl.frontier[1] = (uint32_t *)(b + o_f1);
@@ -670,7 +669,6 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     pl.qcent = (uint16_t *)(b + o_qcent); pl.qsq = (float *)(b + o_qsq);
     pl.rc_pos = (uint32_t *)(b + o_rcp); pl.rc_dist = (float *)(b + o_rcd); pl.rc_max = (float *)(b + o_rcm);
     pl.rflag = (uint32_t *)(b + o_rfl); pl.rc_cnt = (uint32_t *)(b + o_rcc);
-    pl.order = (uint32_t *)(b + o_ord);
     pl.pair_info = (uint32_t *)(b + o_pi); pl.pair_parent = (uint32_t *)(b + o_pp); pl.pair_sorted = (uint32_t *)(b + o_ps); pl.pair_slot = (uint32_t *)(b + o_pl);
     pl.small_flag = (uint32_t *)(b + o_sf);
     pl.grp_cnt = (uint32_t *)(b + o_gc); pl.grp_poff = (uint32_t *)(b + o_gp); pl.grp_ioff = (uint32_t *)(b + o_gi);
@@ -680,6 +678,7 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     pl.sel_ord = (uint64_t *)(b + o_sord);
     pl.qnorm = (float *)(b + o_qn);
     pl.level_fc = (uint32_t *)(b + o_lfc);
+    pl.leaf_tables = (uint32_t *)(b + o_ltb);
     return off;
 }
 
@@ -1038,26 +1037,28 @@ extern "C" int cuddle_debug_stamps(uint64_t *out, uint32_t n_blocks) {
 static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32_t nq, hipStream_t s,
                                         uint32_t *ghist = nullptr) {
     const IndexDev &v = ix->dev;
-    // candidate counts and the block order, longest queries first (nq <= kMaxChunk = 4096)
+    // candidate counts, then every query's leaf tables written in block order, longest queries first
+    // (nq <= kMaxChunk = 4096)
     mark(ix, s, CUDDLE_STAGE_SCAN_PREP);
+    const uint32_t tstride = pl.lstride + 4;
     hipLaunchKernelGGL(cand_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, pl.leaves, pl.lstride, pl.lcount, nq,
                        pl.cand_count);
-    hipLaunchKernelGGL(order_by_work_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, pl.cand_count, nq, pl.order);
+    hipLaunchKernelGGL(scan_tables_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, pl.leaves, pl.lstride, pl.lcount,
+                       pl.cand_count, nq, pl.leaf_tables, tstride);
     mark(ix, s, CUDDLE_STAGE_SCAN);
     if (v.code_kind == CUDDLE_CODE_RABITQ) {
         const float *rq = reinterpret_cast<const float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
-        hipLaunchKernelGGL(scan_select_rabitq_kernel, dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, rq, qn, pl.leaves,
-                           pl.lstride, pl.lcount, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap,
-                           reinterpret_cast<float *>(pl.gdist), pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count,
-                           pl.cand_count, pl.order);
+        hipLaunchKernelGGL(scan_select_rabitq_kernel, dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, rq, qn, pl.leaf_tables,
+                           tstride, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, reinterpret_cast<float *>(pl.gdist),
+                           pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count);
         hipLaunchKernelGGL(selection_sort_f32_kernel, dim3(nq), dim3(256), (size_t)host_next_pow2(pl.sstride) * 8, s,
                            pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.sel_ord);
         HIP_TRY(hipGetLastError());
         return CUDDLE_OK;
     }
     hipLaunchKernelGGL(scan_kernel_for(v.dim, v.words), dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, pl.qcodes,
-                       pl.leaves, pl.lstride, pl.lcount, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, (void *)pl.gdist,
-                       pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, pl.order, ghist);
+                       pl.leaf_tables, tstride, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, (void *)pl.gdist, pl.cstride,
+                       pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, ghist);
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
 }

@@ -277,7 +277,7 @@ __device__ __forceinline__ void ordered_threshold_compact(uint32_t C, uint32_t T
 // readable up to the next multiple of 4 bytes): the same result as ordered_threshold_compact, but
 // every lane walks its own contiguous run of 32-bit words, so the loop body has no cross-lane
 // operation: pass 1 counts keys < T and == T per lane, one wave scan and a per-wave table turn the
-// counts into each lane's starting ranks, pass 2 calls emit(i, key, rank) for the selected items.
+// counts into each lane's starting ranks, pass 2 calls emit(i, rank) for the selected items.
 // The words of a lane are an odd number apart from the next lane's (no LDS bank conflicts).
 // Keys are compared a word at a time: for fields of B bits and n <= 2^(B-1),
 // ((L + n * ONES) - (x & L)) & ~x & H has a field's top bit set exactly when the field is < n
@@ -329,52 +329,79 @@ __device__ __forceinline__ void chunked_threshold_select(WordPtr words, uint32_t
             }
         }
     }
+    CUDDLE_STAMP(1, 5);
     const uint32_t incl_lt = wave_inclusive_sum(n_lt), incl_tie = wave_inclusive_sum(n_tie);
     if (lane == 63) {
         wtmp[w] = incl_lt;
         wtmp[nw + w] = incl_tie;
     }
     __syncthreads();
+    CUDDLE_STAMP(1, 6);
     uint32_t lt_run = incl_lt - n_lt, tie_run = incl_tie - n_tie;
     for (uint32_t v = 0; v < w; ++v) {
         lt_run += wtmp[v];
         tie_run += wtmp[nw + v];
     }
-    for (uint32_t j0 = wb; j0 < we; j0 += 4) {
-        uint32_t v[4];
+    if (swar) {
+        // The selected keys are few, so a lane first folds the outcome of a whole group of its words into two
+        // bit masks (one bit per key: below the threshold / equal to it) and then walks the set bits of the
+        // group once: the walk is as long as the busiest lane's selection in the group, not the sum over the
+        // words of the busiest lane per word.
+        constexpr uint32_t G = 32 / EPW; // words per group: 32 keys
+        for (uint32_t j0 = wb; j0 < we; j0 += G) {
+            uint32_t v[G];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = load(j0 + u);
+            for (uint32_t u = 0; u < G; ++u) v[u] = load(j0 + u);
+            uint32_t mlt = 0, mtie = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (swar) {
+            for (uint32_t u = 0; u < G; ++u) {
                 const uint32_t lo = v[u] & L, nx = ~v[u] & H;
                 const uint32_t lt = (a_lt - lo) & nx, tie = ((a_le - lo) & nx) ^ lt;
-                // ties stop mattering to this lane once the budget is used up before it
-                uint32_t m = lt | (tie_run < budget ? tie : 0u);
-                while (m) {
-                    const uint32_t bit = __ffs(m) - 1, e = bit / BITS;
-                    const uint32_t kv = (v[u] >> (e * BITS)) & MASK, i = (j0 + u) * EPW + e;
-                    if ((lt >> bit) & 1u) {
-                        emit(i, kv, lt_run + min(tie_run, budget));
-                        ++lt_run;
-                    } else {
-                        if (tie_run < budget) emit(i, kv, lt_run + tie_run);
-                        ++tie_run;
-                    }
-                    m &= m - 1;
+                // the top bit of every field -> one bit per field
+                uint32_t clt, ctie;
+                if (BITS == 8) {
+                    clt = ((lt >> 7) & 1u) | ((lt >> 14) & 2u) | ((lt >> 21) & 4u) | ((lt >> 28) & 8u);
+                    ctie = ((tie >> 7) & 1u) | ((tie >> 14) & 2u) | ((tie >> 21) & 4u) | ((tie >> 28) & 8u);
+                } else {
+                    clt = ((lt >> 15) & 1u) | ((lt >> 30) & 2u);
+                    ctie = ((tie >> 15) & 1u) | ((tie >> 30) & 2u);
                 }
-            } else {
+                mlt |= clt << (u * EPW);
+                mtie |= ctie << (u * EPW);
+            }
+            // ties stop mattering to this lane once the budget is used up before it
+            uint32_t m = mlt | (tie_run < budget ? mtie : 0u);
+            while (m) {
+                const uint32_t bit = __ffs(m) - 1, i = j0 * EPW + bit;
+                if ((mlt >> bit) & 1u) {
+                    emit(i, lt_run + min(tie_run, budget));
+                    ++lt_run;
+                } else {
+                    if (tie_run < budget) emit(i, lt_run + tie_run);
+                    ++tie_run;
+                }
+                m &= m - 1;
+            }
+        }
+    } else {
+        for (uint32_t j0 = wb; j0 < we; j0 += 4) {
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = load(j0 + u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
 #pragma unroll
                 for (uint32_t e = 0; e < EPW; ++e) {
                     const uint32_t kv = (v[u] >> (e * BITS)) & MASK;
                     const bool lt = kv < T, tie = kv == T;
-                    if (lt || (tie && tie_run < budget)) emit((j0 + u) * EPW + e, kv, lt_run + min(tie_run, budget));
+                    if (lt || (tie && tie_run < budget)) emit((j0 + u) * EPW + e, lt_run + min(tie_run, budget));
                     lt_run += lt ? 1u : 0u;
                     tie_run += tie ? 1u : 0u;
                 }
             }
         }
     }
+    CUDDLE_STAMP(1, 7);
     __syncthreads();
 }
 
@@ -838,6 +865,43 @@ __device__ __forceinline__ uint32_t scan_load_leaves(const IndexDev &ix, const S
     return s.lscan[nl];
 }
 
+// The same from the tables scan_tables_kernel prepared for this block (tb: four rows of tstride u32), in
+// two steps. scan_copy_tables: one round of coalesced copies whose length does not depend on anything
+// loaded before (rows are copied whole, lcap + 1 entries; the query number and its leaf count come with
+// them), then a barrier. scan_build_tiles: cuts the leaves into 64-vector tiles, then a barrier; returns
+// the number of candidates. All threads call both.
+__device__ __forceinline__ void scan_copy_tables(const ScanLds &s, const uint32_t *tb, uint32_t tstride, uint32_t lcap,
+                                                 uint32_t *q_out, uint32_t *nl_out) {
+    for (uint32_t t = threadIdx.x; t <= lcap; t += blockDim.x) {
+        s.lscan[t] = tb[tstride + t];
+        s.ltile[t] = tb[2 * tstride + t];
+        if (t < lcap) {
+            s.lbeg[t] = tb[t];
+            s.lcode[t] = tb[3 * tstride + t];
+        }
+    }
+    if (threadIdx.x < 2) s.misc[4 + threadIdx.x] = tb[tstride - 2 + threadIdx.x];
+    __syncthreads();
+    *q_out = s.misc[4];
+    *nl_out = min(s.misc[5], lcap);
+}
+
+__device__ __forceinline__ uint32_t scan_build_tiles(const ScanLds &s, uint32_t nl, uint32_t tcap, uint32_t *ntiles) {
+    for (uint32_t t = threadIdx.x; t < nl; t += blockDim.x) {
+        const uint32_t tb0 = s.ltile[t], te = s.ltile[t + 1];
+        const uint32_t base = s.lscan[t], n = s.lscan[t + 1] - base;
+        for (uint32_t c = tb0; c < te && c < tcap; ++c) {
+            const uint32_t first = (c - tb0) << 6;
+            s.tiles[c] = (t << 12) | (c - tb0);
+            s.tinfo[c] = ((base + first) << 7) | min(64u, n - first);
+            if (s.tcode) s.tcode[c] = s.lcode[t] + first;
+        }
+    }
+    __syncthreads();
+    *ntiles = min(s.ltile[nl], tcap);
+    return s.lscan[nl];
+}
+
 // Leaf slot that contains scan position i (largest s with lscan[s] <= i, skipping empty leaves).
 __device__ __forceinline__ uint32_t scan_slot_of(const uint32_t *lscan, uint32_t nl, uint32_t i) {
     uint32_t lo = 0, hi = nl; // invariant: lscan[lo] <= i < lscan[hi]
@@ -936,11 +1000,20 @@ cand_count_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const u
     if (lane == 0) cand_count[q] = c;
 }
 
-// order[i] = the query with the i-th most candidates (ties by query number). The scan kernels
-// process queries in this order so that the longest blocks start first and the tail of the launch
-// is made of short ones. One wave per query counts the queries that precede it.
+// What a scan block needs to know about its query, prepared where every query of the batch is in
+// flight at once instead of at the head of every scan block (dependent gathers through the node
+// arrays, prefix sums). One wave per query q:
+//   rank = number of queries with more candidates (ties by query number): the scan kernel's block
+//          `rank` takes this query, so that the longest blocks start first and the tail of the launch
+//          is made of short ones;
+//   tables[rank] = four rows of tstride u32 (tstride >= lstride + 3), per slot of the query's leaf
+//          list: the leaf's first position | exclusive prefix sums of the leaf sizes (entry nl = the
+//          candidate count) | exclusive prefix sums of the leaves' 64-vector tile counts (entry nl =
+//          the total) | the leaf's code offset. Row 0 ends with the header: [tstride - 2] = q,
+//          [tstride - 1] = nl.
 __global__ void __launch_bounds__(256)
-order_by_work_kernel(const uint32_t *cand_count, uint32_t nq, uint32_t *order) {
+scan_tables_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const uint32_t *lcount, const uint32_t *cand_count,
+                   uint32_t nq, uint32_t *tables, uint32_t tstride) {
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq) return;
     const uint32_t mine = cand_count[q];
@@ -951,10 +1024,38 @@ order_by_work_kernel(const uint32_t *cand_count, uint32_t nq, uint32_t *order) {
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
-    if (lane == 0) order[before] = q;
+    const uint32_t nl = min(lcount[q], lstride);
+    uint32_t *tb = tables + (uint64_t)before * 4 * tstride;
+    uint32_t run_c = 0, run_t = 0;
+    for (uint32_t t0 = 0; t0 < nl; t0 += 64) { // wave-uniform trip count
+        const uint32_t t = t0 + lane;
+        uint32_t b = 0, n = 0, co = 0;
+        if (t < nl) {
+            const uint32_t node = leaves[(uint64_t)q * lstride + t];
+            b = ix.vec_off[node];
+            n = ix.vec_off[node + 1] - b;
+            co = ix.code_off[node];
+        }
+        const uint32_t tl = (n + 63) >> 6;
+        const uint32_t ic = wave_inclusive_sum(n), it = wave_inclusive_sum(tl);
+        if (t < nl) {
+            tb[t] = b;
+            tb[tstride + t] = run_c + ic - n;
+            tb[2 * tstride + t] = run_t + it - tl;
+            tb[3 * tstride + t] = co;
+        }
+        run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
+        run_t += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
+    }
+    if (lane == 0) {
+        tb[tstride + nl] = run_c;
+        tb[2 * tstride + nl] = run_t;
+        tb[tstride - 2] = q;
+        tb[tstride - 1] = nl;
+    }
 }
 
-// One block per query (queries taken in `order`, longest first). Phase 1 streams the planar codes
+// One block per query (block b takes the query scan_tables_kernel ranked b-th by work, longest first). Phase 1 streams the planar codes
 // of every reached leaf (tiles of 64 vectors, lane = vector), XOR + popcount against the query
 // code, and keeps each candidate's Hamming distance (DistT = u8 when dim < 255, else u16; in LDS
 // when the query's candidates fit in dist_cap, else in the global spill buffer) while building a
@@ -971,22 +1072,23 @@ order_by_work_kernel(const uint32_t *cand_count, uint32_t nq, uint32_t *order) {
 // keep more loads in flight per wave instead and take the registers they need.
 template <class DistT, int PAIRS, bool TAIL, int U>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((PAIRS == 1 && !TAIL) ? 8 : 1)))
-scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *leaves, uint32_t lstride,
-                           const uint32_t *lcount, uint32_t lcap, uint32_t tcap, uint32_t rerank_k, uint32_t dist_cap,
-                           void *gdist_v, uint32_t gdist_stride, uint32_t *sel_pos, uint32_t *sel_key,
-                           uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count, const uint32_t *order,
-                           uint32_t *ghist) {
+scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *tables, uint32_t tstride, uint32_t lcap,
+                           uint32_t tcap, uint32_t rerank_k, uint32_t dist_cap, void *gdist_v, uint32_t gdist_stride,
+                           uint32_t *sel_pos, uint32_t *sel_key, uint32_t sel_stride, uint32_t *sel_count,
+                           uint32_t *cand_count, uint32_t *ghist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t q = order ? order[blockIdx.x] : blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const uint32_t D = ix.dim, W = ix.words;
     ScanLds s = scan_lds_carve(smem, D, W, lcap, tcap, PAIRS == 1 && !TAIL);
     CUDDLE_STAMP(1, 0);
-    const uint32_t nl = min(lcount[q], lcap);
     for (uint32_t i = tid; i < D + 2; i += blockDim.x) s.hist[i] = 0;
-    for (uint32_t i = tid; i < W; i += blockDim.x) s.qw[i] = qcodes[(uint64_t)q * W + i];
-    uint32_t ntiles = 0;
-    const uint32_t C = scan_load_leaves(ix, s, leaves + (uint64_t)q * lstride, nl, tcap, &ntiles);
+    uint32_t ntiles = 0, q, nl;
+    scan_copy_tables(s, tables + (uint64_t)blockIdx.x * 4 * tstride, tstride, lcap, &q, &nl);
+    // the query's code travels while the tile table is built (W <= blockDim.x for every supported dimension)
+    const uint64_t my_qw = tid < W ? qcodes[(uint64_t)q * W + tid] : 0ull;
+    for (uint32_t i = blockDim.x + tid; i < W; i += blockDim.x) s.qw[i] = qcodes[(uint64_t)q * W + i];
+    if (tid < W) s.qw[tid] = my_qw;
+    const uint32_t C = scan_build_tiles(s, nl, tcap, &ntiles);
     if (tid == 0) cand_count[q] = C;
     if (C == 0) {
         if (tid == 0) sel_count[q] = 0;
@@ -1059,16 +1161,15 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
     // leaf-contiguous positions by all threads.
     uint32_t *sp = sel_pos + (uint64_t)q * sel_stride, *sk = sel_key + (uint64_t)q * sel_stride;
     const uint32_t nsel = min(min(C, rerank_k), sel_stride);
-    uint32_t *stg = s.tiles;
+    // (typed as an LDS pointer: a pointer that may be LDS or global turns every staged store into a flat instruction)
+    LdsU32 *stg = (LdsU32 *)s.tiles;
     const bool stage_lds = nsel <= ((PAIRS == 1 && !TAIL) ? 3u : 2u) * scan_pad4(tcap);
-    chunked_threshold_select<DistT>(
-        dist_words, C, T, budget,
-        [&](uint32_t i, uint32_t, uint32_t rank) {
-            if (rank < nsel) {
-                if (stage_lds) stg[rank] = i; else sp[rank] = i;
-            }
-        },
-        s.wtmp);
+    if (stage_lds)
+        chunked_threshold_select<DistT>(
+            dist_words, C, T, budget, [&](uint32_t i, uint32_t rank) { if (rank < nsel) stg[rank] = i; }, s.wtmp);
+    else
+        chunked_threshold_select<DistT>(
+            dist_words, C, T, budget, [&](uint32_t i, uint32_t rank) { if (rank < nsel) sp[rank] = i; }, s.wtmp);
     if (!stage_lds) {
         __threadfence();
         __syncthreads();

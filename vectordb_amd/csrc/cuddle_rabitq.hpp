@@ -152,22 +152,21 @@ __device__ __forceinline__ RabitqLds rabitq_lds_carve(unsigned char *smem, uint3
 // pattern as key. Estimates live in LDS (or the global spill buffer when a query has more than
 // dist_cap candidates).
 __global__ void __launch_bounds__(512)
-scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_all, const uint32_t *leaves,
-                          uint32_t lstride, const uint32_t *lcount, uint32_t lcap, uint32_t tcap, uint32_t rerank_k,
+scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_all, const uint32_t *tables,
+                          uint32_t tstride, uint32_t lcap, uint32_t tcap, uint32_t rerank_k,
                           uint32_t dist_cap, float *gest, uint32_t gest_stride, uint32_t *sel_pos, uint32_t *sel_key,
-                          uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count, const uint32_t *order) {
+                          uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t q = order ? order[blockIdx.x] : blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const uint32_t D = ix.dim, W32 = ix.words32;
     RabitqLds r = rabitq_lds_carve(smem, D, lcap, tcap);
     const ScanLds &s = r.s;
-    const uint32_t nl = min(lcount[q], lcap);
-    const float qnorm = qnorm_all[q];
     CUDDLE_STAMP(6, 0);
+    uint32_t ntiles = 0, q, nl;
+    scan_copy_tables(s, tables + (uint64_t)blockIdx.x * 4 * tstride, tstride, lcap, &q, &nl);
+    const float qnorm = qnorm_all[q];
     rabitq_stage_query(rq_all + (uint64_t)q * D, D, qnorm, r.rq, r.qsign);
-    uint32_t ntiles = 0;
-    const uint32_t C = scan_load_leaves(ix, s, leaves + (uint64_t)q * lstride, nl, tcap, &ntiles);
+    const uint32_t C = scan_build_tiles(s, nl, tcap, &ntiles);
     if (tid == 0) cand_count[q] = C;
     if (C == 0) {
         if (tid == 0) sel_count[q] = 0;
