@@ -134,6 +134,10 @@ typedef struct cuddle_stats {
     uint32_t max_leaves;             /* max over queries */
     uint32_t tree_levels;            /* routing iterations executed */
     uint32_t route_fallbacks;        /* queries x levels re-routed by the all-exact kernel */
+    /* RaBitQ phase 1: candidates whose estimate was evaluated in the reference's sequential arithmetic
+     * (the others were excluded by a proven bound), and queries that evaluated all of theirs */
+    uint64_t rabitq_exact_estimates;
+    uint64_t rabitq_exact_all_queries;
 } cuddle_stats;
 
 /* Stage indices for cuddle_stage_times(). */

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     assert C.sizeof(_ffi.IndexDesc) == 32 + 8 * 8 + 8 + 4 * 8  # header fields, 8-byte aligned
-    assert C.sizeof(_ffi.Stats) == 40
+    assert C.sizeof(_ffi.Stats) == 56
 
 
 def test_no_gpu_fails_loudly():

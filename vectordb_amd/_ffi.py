@@ -86,6 +86,8 @@ class Stats(C.Structure):
         ("max_leaves", C.c_uint32),
         ("tree_levels", C.c_uint32),
         ("route_fallbacks", C.c_uint32),
+        ("rabitq_exact_estimates", C.c_uint64),
+        ("rabitq_exact_all_queries", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -126,6 +126,7 @@ struct DevBuf {
 struct DevStats { // accumulated on device by stats_accum_kernel
     unsigned long long leaves, scanned, reranked;
     uint32_t max_cand, max_leaves, fallbacks, pad1;
+    unsigned long long rq_exact, rq_exact_all; // RaBitQ scan: candidates evaluated exactly, queries that evaluated all of theirs
 };
 
 // Work-space layout of one chunk of queries.
@@ -639,7 +640,7 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t qc = pl.qc;
-    const size_t dist_bytes = v.code_kind == CUDDLE_CODE_BINARY ? (v.dim < 255 ? 1 : 2) : 4; // u8 / u16 Hamming, f32 estimates
+    const size_t dist_bytes = v.code_kind == CUDDLE_CODE_BINARY ? (v.dim < 255 ? 1 : 2) : 8; // u8 / u16 Hamming; f32 estimates + f32 lower bounds
     size_t o_qcodes = carve(qc * std::max<uint32_t>(v.words, v.dim + 2) * 8); // binary: W u64; RaBitQ: dim+2 floats
     size_t o_f0 = carve(qc * pl.fstride * 4), o_f1 = carve(qc * pl.fstride * 4);
     size_t o_fc0 = carve(qc * 4), o_fc1 = carve(qc * 4);
@@ -724,6 +725,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     // latency-bound prologue/selection phases of one query overlap the streaming of others
     // (two-word codes are built for 8 waves per SIMD: whole-CU occupancy with 512-thread blocks)
     pl.scan_threads = (pl.cstride <= 16384 && v.words != 2) ? 256 : kScanThreads;
+    if (v.code_kind == CUDDLE_CODE_RABITQ) pl.scan_threads = 1024; // two blocks of 16 waves per CU: the LDS holds no more blocks, the registers this many waves
     if (const char *e = getenv("CUDDLE_SCAN_THREADS")) {  // tuning aid; the kernels are bounded at 512 threads
         const int t = atoi(e);
         if (t >= 64 && t <= (int)kScanThreads && t % 64 == 0) pl.scan_threads = (uint32_t)t;
@@ -1047,10 +1049,12 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
                        pl.cand_count, nq, pl.leaf_tables, tstride);
     mark(ix, s, CUDDLE_STAGE_SCAN);
     if (v.code_kind == CUDDLE_CODE_RABITQ) {
+        static const bool rabitq_exact_all = getenv("CUDDLE_RABITQ_EXACT_ALL") != nullptr; // A/B aid: no bounds, every estimate exact
         const float *rq = reinterpret_cast<const float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
         hipLaunchKernelGGL(scan_select_rabitq_kernel, dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, rq, qn, pl.leaf_tables,
                            tstride, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, reinterpret_cast<float *>(pl.gdist),
-                           pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count);
+                           pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, rabitq_exact_all ? 1u : 0u,
+                           &ix->d_stats->rq_exact);
         hipLaunchKernelGGL(selection_sort_f32_kernel, dim3(nq), dim3(256), (size_t)host_next_pow2(pl.sstride) * 8, s,
                            pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.sel_ord);
         HIP_TRY(hipGetLastError());
@@ -1176,6 +1180,8 @@ static cuddle_status read_stats(cuddle_index *ix, cuddle_stats *st) {
     st->max_leaves = h.max_leaves;
     st->tree_levels = ix->last_levels;
     st->route_fallbacks = h.fallbacks;
+    st->rabitq_exact_estimates = h.rq_exact;
+    st->rabitq_exact_all_queries = h.rq_exact_all;
     return CUDDLE_OK;
 }
 

@@ -5,6 +5,8 @@
 // products), so estimates are bit-identical to the reference arithmetic.
 #pragma once
 
+#include <type_traits>
+
 #include "cuddle_route.hpp"
 
 namespace cuddle {
@@ -78,25 +80,27 @@ __device__ __forceinline__ float rabitq_estimate(const uint32_t *codes, uint32_t
     const LdsF32 *la = (const LdsF32 *)arq;
     const LdsU32 *ls = (const LdsU32 *)qsign;
     float sum = 0.f;
-    for (uint32_t w0 = 0; w0 < words32; w0 += 8) { // eight code words in flight per lane
+    const uint32_t nfull = dim >> 5; // words whose 32 bits all belong to the vector
+    uint32_t w = 0;
+    // straight-line chunks (no condition between a load and its use, or the compiler sinks every load next to
+    // its use and waits for each in turn): eight code words in flight per lane
+    for (; w + 8 <= nfull; w += 8) {
         uint32_t cw[8];
 #pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) cw[u] = w0 + u < words32 ? codes[(uint64_t)(w0 + u) * n + i] : 0u;
+        for (uint32_t u = 0; u < 8; ++u) cw[u] = codes[(uint64_t)(w + u) * n + i];
 #pragma unroll
         for (uint32_t u = 0; u < 8; ++u) {
-            const uint32_t w = w0 + u;
-            if (w >= words32) break;
-            const uint32_t sg = ls[w] ^ ~cw[u];
-            const uint32_t lim = min(32u, dim - 32u * w);
-            if (lim == 32) {
+            const uint32_t sg = ls[w + u] ^ ~cw[u];
 #pragma unroll
-                for (uint32_t b = 0; b < 32; ++b)
-                    sum += __uint_as_float(((sg << (31 - b)) & 0x80000000u) | __float_as_uint(la[32 * w + b])); // v_and_or_b32
-            } else {
-                for (uint32_t b = 0; b < lim; ++b)
-                    sum += __uint_as_float(((sg << (31 - b)) & 0x80000000u) | __float_as_uint(la[32 * w + b]));
-            }
+            for (uint32_t b = 0; b < 32; ++b)
+                sum += __uint_as_float(((sg << (31 - b)) & 0x80000000u) | __float_as_uint(la[32 * (w + u) + b]));
         }
+    }
+    for (; w < words32; ++w) {
+        const uint32_t sg = ls[w] ^ ~codes[(uint64_t)w * n + i];
+        const uint32_t lim = min(32u, dim - 32u * w);
+        for (uint32_t b = 0; b < lim; ++b)
+            sum += __uint_as_float(((sg << (31 - b)) & 0x80000000u) | __float_as_uint(la[32 * w + b]));
     }
     const float est_ip = sum / ipoo;
     const float dn = 2.0f - 2.0f * est_ip;
@@ -119,9 +123,29 @@ __device__ __forceinline__ void rabitq_stage_query(const float *rq, uint32_t dim
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// phase 1 in two steps: a cheap bound for every candidate, the exact estimate for the few that matter
+// ---------------------------------------------------------------------------------------------
+// The exact estimate costs one dependent f32 add per code bit (the reference's sequential sum), and only
+// about one candidate in ten is selected. So every candidate first gets an approximate estimate from
+// integer arithmetic with a proven error bound, and the exact sum is evaluated only where the bounds
+// leave a choice:
+//   * the query's magnitudes |rq_i| are quantised to kRqPlanes bits, |rq_i| ~ delta * v_i, and kept as bit
+//     planes; with d_i = 1 where the code bit and the sign of rq_i make term i negative,
+//       ip~ = delta * (sum_i v_i - 2 sum_p 2^p popcount(d & plane_p))            (exact integers),
+//     and |ip~ - ip| <= B_q = sum_i ||rq_i| - delta v_i| + the rounding of the reference's f32 sum;
+//   * est~ = (2 - 2 ip~ / ip_oo) norm qnorm, |est~ - est| <= E_c = norm_c (a_q + b_q / ip_oo_c);
+//   * tau = the rerank_k-th smallest upper bound est~ + E: at least rerank_k candidates have their exact
+//     estimate <= tau, so a candidate whose lower bound est~ - E is > tau cannot be selected;
+//   * the others (the selection and a band around its boundary) get the exact sequential-order
+//     estimate, two candidates per lane in packed f32 adds, and the selection runs on those values:
+//     the same set, order and keys as evaluating every candidate exactly.
+constexpr uint32_t kRqPlanes = 12;
+constexpr uint32_t kRqListCap = 4096; // candidates whose exact estimate is needed; more: every candidate is evaluated exactly
+
 inline size_t rabitq_scan_lds_bytes(uint32_t dim, uint32_t lcap, uint32_t tcap, uint32_t dist_cap) {
     return scan_lds_bytes(0, 0, lcap, tcap, 0) + 256 * 4 + (size_t)((dim + 3) & ~3u) * 4 + (size_t)((dim + 63) / 64) * 8 +
-           (size_t)dist_cap * 4 + 64;
+           (size_t)kRqPlanes * 2 * ((dim + 63) / 64) * 4 + (size_t)kRqListCap * 4 + 32 * 4 + (size_t)dist_cap * 4 + 96;
 }
 
 struct RabitqLds {
@@ -129,6 +153,9 @@ struct RabitqLds {
     uint32_t *rhist; // [256] radix-select histogram
     float *rq;       // [dim]  |rotated query|
     uint32_t *qsign; // [2 * ceil(dim / 64)] sign bits of the rotated query
+    uint32_t *planes; // [2 * ceil(dim / 64)][kRqPlanes] bit planes of the quantised magnitudes, the planes of a word together
+    uint32_t *list;  // [kRqListCap] scan positions of the candidates to evaluate exactly
+    float *fsc;      // [16] per-query scalars of the bound; [16..31] the same memory seen as u32 counters
     float *est;      // [dist_cap]
 };
 
@@ -140,22 +167,201 @@ __device__ __forceinline__ RabitqLds rabitq_lds_carve(unsigned char *smem, uint3
     r.rhist = p; p += 256;
     r.rq = reinterpret_cast<float *>(p); p += (dim + 3) & ~3u;
     r.qsign = p; p += 2 * ((dim + 63) / 64);
+    r.planes = p; p += kRqPlanes * 2 * ((dim + 63) / 64);
+    r.list = p; p += kRqListCap;
+    r.fsc = reinterpret_cast<float *>(p); p += 32;
     p = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
     r.est = reinterpret_cast<float *>(p);
     return r;
 }
 
-// One block per query: estimated distance of every vector of every reached leaf
-// (compute_rabitq_distances / collect_leaf_candidates, hierarchical_with_rabitq.rs:581-619), then
-// the rerank_k smallest by (estimate, scan position) — the first rerank_k of the reference's
-// stable sort (select_top_candidates, :623-633) — emitted in scan order with the estimate's bit
-// pattern as key. Estimates live in LDS (or the global spill buffer when a query has more than
-// dist_cap candidates).
-__global__ void __launch_bounds__(512)
+// Bit 31 of x, bits 0..30 of mag (one v_bfi_b32; the mask has to sit in a scalar register).
+__device__ __forceinline__ float rabitq_signed(uint32_t x, float mag) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0x7FFFFFFFu), "v"(__float_as_uint(mag)), "v"(x));
+    return __uint_as_float(r);
+}
+
+// compute_inner_product_fast (rabitq.rs:298-321) for TWO vectors at once: the sequential sums of both run
+// in the two halves of packed f32 adds (each half the same IEEE addition as the scalar sum), the sign of
+// a term comes from bit 31 of the bit-reversed (query sign ^ ~code) word, which a 64-bit shift moves on
+// for both vectors in one instruction. ca / cb: the vectors' code columns (word w at ca[w * na]).
+__device__ __forceinline__ void rabitq_ip_pair(const uint32_t *ca, uint32_t na, const uint32_t *cb, uint32_t nb, uint32_t dim,
+                                               uint32_t words32, const LdsF32 *la, const LdsU32 *ls, float &ipa, float &ipb) {
+    v2f sum = {0.f, 0.f};
+    const uint32_t nfull = dim >> 5;
+    uint32_t w = 0;
+    auto word = [&](uint32_t w, uint32_t wa, uint32_t wb, uint32_t lim) {
+        const uint32_t q = ls[w];
+        uint64_t y = ((uint64_t)__builtin_bitreverse32(q ^ ~wb) << 32) | __builtin_bitreverse32(q ^ ~wa);
+        if (lim == 32) {
+#pragma unroll
+            for (uint32_t b = 0; b < 32; ++b) {
+                const float m = la[32 * w + b];
+                const v2f t = {rabitq_signed((uint32_t)y, m), rabitq_signed((uint32_t)(y >> 32), m)};
+                sum += t;
+                y <<= 1;
+            }
+        } else {
+            for (uint32_t b = 0; b < lim; ++b) {
+                const float m = la[32 * w + b];
+                const v2f t = {rabitq_signed((uint32_t)y, m), rabitq_signed((uint32_t)(y >> 32), m)};
+                sum += t;
+                y <<= 1;
+            }
+        }
+    };
+    for (; w + 8 <= nfull; w += 8) { // straight-line chunks: sixteen loads in flight, no condition before their use
+        uint32_t wa[8], wb[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            wa[u] = ca[(uint64_t)(w + u) * na];
+            wb[u] = cb[(uint64_t)(w + u) * nb];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) word(w + u, wa[u], wb[u], 32);
+    }
+    for (; w < words32; ++w) word(w, ca[(uint64_t)w * na], cb[(uint64_t)w * nb], min(32u, dim - 32u * w));
+    ipa = sum.x;
+    ipb = sum.y;
+}
+
+// estimate_distance_fast (rabitq.rs:335-363) given the inner product.
+__device__ __forceinline__ float rabitq_estimate_from_ip(float ip, float qnorm, float norm, float ipoo) {
+    if (qnorm < 1e-10f) return norm * norm;
+    if (norm < 1e-10f) return qnorm * qnorm;
+    const float est_ip = ip / ipoo;
+    const float dn = 2.0f - 2.0f * est_ip;
+    return dn * norm * qnorm;
+}
+
+// Quantises the staged magnitudes (r.rq) to kRqPlanes bits and leaves the per-query scalars of the bound in
+// r.fsc: [0] delta, [1] a_q, [2] b_q (E_c = norm_c * (a_q + b_q / ip_oo_c)), and in the u32 view [16] = sum of
+// the quantised values. All threads call (whole waves); barriers inside; the caller has synchronised after
+// rabitq_stage_query.
+__device__ __forceinline__ void rabitq_quantise_query(const RabitqLds &r, uint32_t dim, float qnorm) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const uint32_t dpad = (dim + 63) & ~63u;
+    uint32_t *isc = reinterpret_cast<uint32_t *>(r.fsc) + 16;
+    float *wsum = reinterpret_cast<float *>(r.rhist); // per-wave partial results (the histogram is free until the selection)
+    float mx = 0.f;
+    for (uint32_t i = tid; i < dim; i += blockDim.x) mx = fmaxf(mx, r.rq[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) wsum[w] = mx;
+    __syncthreads();
+    mx = 0.f;
+    for (uint32_t v = 0; v < nw; ++v) mx = fmaxf(mx, wsum[v]);
+    __syncthreads();
+    constexpr uint32_t VMAX = (1u << kRqPlanes) - 1;
+    const float delta = mx / (float)VMAX, inv = mx > 0.f ? (float)VMAX / mx : 0.f;
+    float res = 0.f, asum = 0.f;
+    uint32_t vsum = 0;
+    for (uint32_t i = tid; i < dpad; i += blockDim.x) {
+        const float a = i < dim ? r.rq[i] : 0.f;
+        uint32_t v = (uint32_t)rintf(a * inv);
+        v = (a == a && v <= VMAX) ? v : (a == a ? VMAX : 0u);
+        res += fabsf(a - delta * (float)v);
+        asum += a;
+        vsum += v;
+#pragma unroll
+        for (uint32_t p = 0; p < kRqPlanes; ++p) {
+            const uint64_t bal = __ballot((v >> p) & 1u);
+            if (lane == 0) {
+                r.planes[(i >> 5) * kRqPlanes + p] = (uint32_t)bal;
+                r.planes[((i >> 5) + 1) * kRqPlanes + p] = (uint32_t)(bal >> 32);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        res += __shfl_xor(res, o, 64);
+        asum += __shfl_xor(asum, o, 64);
+        vsum += __shfl_xor(vsum, o, 64);
+    }
+    if (lane == 0) {
+        wsum[w] = res;
+        wsum[16 + w] = asum;
+        reinterpret_cast<uint32_t *>(wsum)[32 + w] = vsum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float R = 0.f, A = 0.f;
+        uint32_t V = 0;
+        for (uint32_t v = 0; v < nw; ++v) {
+            R += wsum[v];
+            A += wsum[16 + v];
+            V += reinterpret_cast<uint32_t *>(wsum)[32 + v];
+        }
+        // |ip~ - ip| <= B: quantisation residue (computed in f32: 0.2 % slack) + the rounding of the reference's
+        // sequential f32 sum and of delta * integer (each below dim * 2^-23 times the sum of magnitudes)
+        const float B = 1.002f * R + ((float)dim + 8.0f) * 1.2e-7f * (A + R);
+        // E_c = norm_c qnorm (2 B / ip_oo + 1e-5 (1 + (A + B) / ip_oo)), 0.1 % slack: the second term covers the
+        // roundings of (2 - 2 ip / ip_oo) norm qnorm in either evaluation and of the bound itself
+        r.fsc[0] = delta;
+        r.fsc[1] = 1.001f * qnorm * 1e-5f;
+        r.fsc[2] = 1.001f * qnorm * (2.0f * B + 1e-5f * (A + B));
+        isc[0] = V;
+    }
+    __syncthreads();
+}
+
+// Upper bound est~ + E (returned) and lower bound est~ - E (lb) of the estimate of vector i of a leaf (codes
+// word-major [w][n]); see the section comment. Both are rounded outwards.
+__device__ __forceinline__ float rabitq_bounds(const uint32_t *codes, uint32_t n, uint32_t i, uint32_t words32,
+                                               const RabitqLds &r, float qnorm, float norm, float ipoo, float &lb) {
+    if (norm < 1e-10f) { // exact (rabitq.rs:342-349)
+        lb = qnorm * qnorm;
+        return lb;
+    }
+    const LdsU32 *ls = (const LdsU32 *)r.qsign;
+    const LdsU32 *pl = (const LdsU32 *)r.planes;
+    uint32_t cnt[kRqPlanes];
+#pragma unroll
+    for (uint32_t p = 0; p < kRqPlanes; ++p) cnt[p] = 0;
+    // straight-line chunks of 16, 8 and 1 code words (no condition between a load and its use, or the compiler
+    // sinks every load next to its use and waits for each in turn): the loop is bound by memory latency
+    auto chunk = [&](uint32_t w, auto ch) {
+        constexpr uint32_t CH = decltype(ch)::value;
+        uint32_t cw[CH];
+#pragma unroll
+        for (uint32_t u = 0; u < CH; ++u) cw[u] = codes[(uint64_t)(w + u) * n + i];
+#pragma unroll
+        for (uint32_t u = 0; u < CH; ++u) {
+            const uint32_t d = ls[w + u] ^ ~cw[u]; // bit i set: term i is negative
+#pragma unroll
+            for (uint32_t p = 0; p < kRqPlanes; ++p) cnt[p] += __popc(d & pl[(w + u) * kRqPlanes + p]);
+        }
+    };
+    uint32_t w = 0;
+    for (; w + 16 <= words32; w += 16) chunk(w, std::integral_constant<uint32_t, 16>());
+    for (; w + 8 <= words32; w += 8) chunk(w, std::integral_constant<uint32_t, 8>());
+    for (; w < words32; ++w) chunk(w, std::integral_constant<uint32_t, 1>());
+    uint32_t K = 0;
+#pragma unroll
+    for (uint32_t p = 0; p < kRqPlanes; ++p) K += cnt[p] << p;
+    const uint32_t V = reinterpret_cast<const uint32_t *>(r.fsc)[16];
+    const float ip = r.fsc[0] * (float)((int)V - 2 * (int)K);
+    const float est = (2.0f - 2.0f * (ip / ipoo)) * norm * qnorm;
+    const float E = norm * (r.fsc[1] + r.fsc[2] / ipoo), round_out = 1e-6f * fabsf(est) + 1e-6f * E;
+    lb = est - E - round_out;
+    return est + E + round_out;
+}
+
+// One block per query (block b takes the query scan_tables_kernel ranked b-th by work): estimated
+// distance of the vectors of every reached leaf (compute_rabitq_distances / collect_leaf_candidates,
+// hierarchical_with_rabitq.rs:581-619), then the rerank_k smallest by (estimate, scan position) — the
+// first rerank_k of the reference's stable sort (select_top_candidates, :623-633) — emitted in scan
+// order with the estimate's bit pattern as key. Bounds first, exact estimates where they leave a choice
+// (section comment above); `exact_all` != 0 evaluates every candidate exactly (A/B and fallback path).
+// Values live in LDS (or the global spill buffer when a query has more than dist_cap candidates).
+// stats: [0] += candidates evaluated exactly, [1] += queries that took the exact-for-all path.
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) // two blocks of 16 waves per CU
 scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_all, const uint32_t *tables,
                           uint32_t tstride, uint32_t lcap, uint32_t tcap, uint32_t rerank_k,
                           uint32_t dist_cap, float *gest, uint32_t gest_stride, uint32_t *sel_pos, uint32_t *sel_key,
-                          uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count) {
+                          uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count, uint32_t exact_all,
+                          unsigned long long *stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const uint32_t D = ix.dim, W32 = ix.words32;
@@ -173,32 +379,98 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
         return;
     }
     const bool use_lds = C <= dist_cap;
-    float *ge = gest + (uint64_t)q * gest_stride;
+    float *ge = gest + (uint64_t)q * 2 * gest_stride; // the query's spill row: estimates | lower bounds
+    float *glb = ge + gest_stride;
+    auto est_at = [&](uint32_t i) -> float { return use_lds ? r.est[i] : ge[i]; };
+    auto est_put = [&](uint32_t i, float v) { if (use_lds) r.est[i] = v; else ge[i] = v; };
+    const bool all = C <= rerank_k;
+    // the bounds pay when a selection has to be made and the query has a direction (a zero query's estimates are norm^2)
+    bool filtered = !exact_all && !all && qnorm >= 1e-10f;
+    uint32_t *isc = reinterpret_cast<uint32_t *>(r.fsc) + 16;
     CUDDLE_STAMP(6, 1);
-    for (uint32_t t = w; t < ntiles; t += nw) {
-        const uint32_t tile = s.tiles[t], sl = tile >> 12, i = ((tile & 4095u) << 6) + lane;
-        const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base;
-        if (i < n) {
-            const uint32_t pos = s.lbeg[sl] + i;
-            float e = rabitq_estimate(ix.rq_codes + (uint64_t)s.lbeg[sl] * W32, n, i, D, W32, r.rq, r.qsign, qnorm,
-                                      ix.rq_norm[pos], ix.rq_ipoo[pos]);
-            if (use_lds) r.est[base + i] = e; else ge[base + i] = e;
+    if (filtered) {
+        rabitq_quantise_query(r, D, qnorm);
+        if (tid == 0) isc[1] = 0; // members
+        for (uint32_t t = w; t < ntiles; t += nw) {
+            const uint32_t tile = s.tiles[t], sl = tile >> 12, i = ((tile & 4095u) << 6) + lane;
+            const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base;
+            if (i < n) {
+                const uint32_t pos = s.lbeg[sl] + i;
+                float lb;
+                est_put(base + i, rabitq_bounds(ix.rq_codes + (uint64_t)s.lbeg[sl] * W32, n, i, W32, r, qnorm, ix.rq_norm[pos],
+                                                ix.rq_ipoo[pos], lb));
+                glb[base + i] = lb;
+            }
         }
+        __syncthreads();
+        CUDDLE_STAMP(6, 2);
+        // tau = the rerank_k-th smallest upper bound
+        uint32_t bdummy;
+        const uint32_t Tub = block_radix_select_aligned(C, rerank_k, [&](uint32_t i) { return f32_key(est_at(i)); }, r.rhist, s.misc,
+                                                        s.wtmp, bdummy);
+        const float tau = f32_from_key(Tub);
+        // members: lower bound <= tau (written so that a NaN anywhere keeps the candidate); the others can never be selected
+        for (uint32_t i = tid; i < C; i += blockDim.x) {
+            if (!(glb[i] > tau) || Tub == 0xFFFFFFFFu) {
+                const uint32_t slot = atomicAdd(&isc[1], 1u);
+                if (slot < kRqListCap) r.list[slot] = i;
+            } else {
+                est_put(i, __builtin_inff());
+            }
+        }
+        __syncthreads();
+        const uint32_t ns = isc[1];
+        if (ns > kRqListCap) {
+            filtered = false; // too many to list: every candidate exactly (below)
+        } else {
+            // exact estimates of the members, two per lane
+            for (uint32_t j = 2 * tid; j < ns; j += 2 * blockDim.x) {
+                const uint32_t ia = r.list[j], ib = r.list[min(j + 1, ns - 1)];
+                const uint32_t sa = scan_slot_of(s.lscan, nl, ia), sb = scan_slot_of(s.lscan, nl, ib);
+                const uint32_t na = s.lscan[sa + 1] - s.lscan[sa], nb = s.lscan[sb + 1] - s.lscan[sb];
+                const uint32_t ka = ia - s.lscan[sa], kb = ib - s.lscan[sb];
+                const uint32_t pa = s.lbeg[sa] + ka, pb = s.lbeg[sb] + kb;
+                float ipa, ipb;
+                rabitq_ip_pair(ix.rq_codes + (uint64_t)s.lbeg[sa] * W32 + ka, na, ix.rq_codes + (uint64_t)s.lbeg[sb] * W32 + kb, nb, D,
+                               W32, (const LdsF32 *)r.rq, (const LdsU32 *)r.qsign, ipa, ipb);
+                est_put(ia, rabitq_estimate_from_ip(ipa, qnorm, ix.rq_norm[pa], ix.rq_ipoo[pa]));
+                if (j + 1 < ns) est_put(ib, rabitq_estimate_from_ip(ipb, qnorm, ix.rq_norm[pb], ix.rq_ipoo[pb]));
+            }
+            if (tid == 0 && stats) atomicAdd(&stats[0], (unsigned long long)ns);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    CUDDLE_STAMP(6, 2);
-    auto key = [&](uint32_t i) -> uint32_t { return f32_key(use_lds ? r.est[i] : ge[i]); };
+    if (!filtered) {
+        for (uint32_t t = w; t < ntiles; t += nw) {
+            const uint32_t tile = s.tiles[t], sl = tile >> 12, i = ((tile & 4095u) << 6) + lane;
+            const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base;
+            if (i < n) {
+                const uint32_t pos = s.lbeg[sl] + i;
+                est_put(base + i, rabitq_estimate(ix.rq_codes + (uint64_t)s.lbeg[sl] * W32, n, i, D, W32, r.rq, r.qsign, qnorm,
+                                                  ix.rq_norm[pos], ix.rq_ipoo[pos]));
+            }
+        }
+        if (tid == 0 && stats) {
+            atomicAdd(&stats[0], (unsigned long long)C);
+            atomicAdd(&stats[1], 1ull);
+        }
+        __syncthreads();
+    }
+    CUDDLE_STAMP(6, 3);
+    auto key = [&](uint32_t i) -> uint32_t { return f32_key(est_at(i)); };
     auto key2 = [&](uint32_t i, uint32_t &) -> uint32_t { return key(i); };
     uint32_t T = 0xFFFFFFFFu, budget = 0;
-    bool all = C <= rerank_k;
-    if (!all) T = block_radix_select(C, rerank_k, key, r.rhist, s.misc, budget);
-    CUDDLE_STAMP(6, 3);
+    if (filtered) // every other candidate holds +inf: the threshold and its tie budget are those of the listed ones
+        T = block_radix_select_aligned(isc[1], rerank_k, [&](uint32_t j) { return f32_key(est_at(r.list[j])); }, r.rhist, s.misc,
+                                       s.wtmp, budget);
+    else if (!all)
+        T = block_radix_select_aligned(C, rerank_k, key, r.rhist, s.misc, s.wtmp, budget);
     uint32_t *sp = sel_pos + (uint64_t)q * sel_stride, *sk = sel_key + (uint64_t)q * sel_stride;
     auto emit = [&](uint32_t i, uint32_t, uint32_t, uint32_t rank) {
         if (rank < sel_stride) {
             uint32_t sl = scan_slot_of(s.lscan, nl, i);
             sp[rank] = s.lbeg[sl] + (i - s.lscan[sl]);
-            sk[rank] = __float_as_uint(use_lds ? r.est[i] : ge[i]);
+            sk[rank] = __float_as_uint(est_at(i));
         }
     };
     if (all) {

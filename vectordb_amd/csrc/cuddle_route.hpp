@@ -66,6 +66,73 @@ __device__ __forceinline__ uint32_t block_radix_select(uint32_t n, uint32_t want
     return prefix;
 }
 
+// block_radix_select whose digits start at the highest bit in which the block's smallest and largest key
+// differ: keys that share their leading bits (floats of one magnitude) would otherwise all count into one
+// bucket of the first passes, one same-address LDS atomic after another. wred: 2 * (blockDim.x / 64) u32.
+template <class KeyFn>
+__device__ __forceinline__ uint32_t block_radix_select_aligned(uint32_t n, uint32_t want, KeyFn key, uint32_t *hist,
+                                                               uint32_t *misc, uint32_t *wred, uint32_t &budget) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+        const uint32_t kv = key(i);
+        kmin = min(kmin, kv);
+        kmax = max(kmax, kv);
+    }
+    kmin = wave_min_u32(kmin);
+    kmax = ~wave_min_u32(~kmax);
+    __syncthreads(); // wred may still be read by an earlier call
+    if (lane == 0) {
+        wred[w] = kmin;
+        wred[nw + w] = kmax;
+    }
+    __syncthreads();
+    for (uint32_t v = 0; v < nw; ++v) {
+        kmin = min(kmin, wred[v]);
+        kmax = max(kmax, wred[nw + v]);
+    }
+    const uint32_t diff = kmin ^ kmax;
+    if (diff == 0) { // all keys equal (or n == 0)
+        budget = want;
+        return kmin;
+    }
+    uint32_t rem = 32 - __clz(diff); // bits still undecided
+    uint32_t prefix = rem == 32 ? 0u : (kmin >> rem) << rem;
+    while (rem > 0) {
+        const uint32_t wbits = min(8u, rem), shift = rem - wbits, dmask = (1u << wbits) - 1;
+        for (uint32_t i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += blockDim.x) {
+            const uint32_t kv = key(i);
+            if (rem == 32 || (kv >> rem) == (prefix >> rem)) atomicAdd(&hist[(kv >> shift) & dmask], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) { // wave 0: prefix-sum the 256 buckets, 4 per lane
+            const uint32_t l = tid;
+            const uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+            const uint32_t s4 = h0 + h1 + h2 + h3;
+            const uint32_t incl = wave_inclusive_sum(s4);
+            const uint64_t hit = __ballot(incl >= want);
+            const uint32_t first = hit ? (uint32_t)__ffsll((unsigned long long)hit) - 1 : 63u;
+            if (l == first) {
+                uint32_t cum = incl - s4, b = 4 * l;
+                if (cum + h0 < want) { cum += h0; ++b;
+                    if (cum + h1 < want) { cum += h1; ++b;
+                        if (cum + h2 < want) { cum += h2; ++b; } } }
+                misc[0] = prefix | (b << shift);
+                misc[1] = want - cum;
+            }
+        }
+        __syncthreads();
+        prefix = misc[0];
+        want = misc[1];
+        rem = shift;
+        __syncthreads();
+    }
+    budget = want;
+    return prefix;
+}
+
 // Optional output of route_expand for the next level's grouped distance kernel: one (query, chosen
 // internal node) pair per selection slot, and the number of pairs per parent node.
 //   info[q * pstride + i]   = (q << 20) | position of the node's first child in the next frontier,
