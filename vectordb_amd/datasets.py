@@ -5,7 +5,8 @@ be downloaded here; synthetic data is always labelled as such).
 Formats: .fvecs/.ivecs — per vector a little-endian i32 dimension then that many f32/i32
 (/root/reference/datasets/sift/loader.rs:10-87); generator .bin — [u32 n][u32 d][f32 ...]
 (/root/reference/datasets/generate_datasets.rs:165-189); raw vector file — count*dim f32, no
-header (/root/reference/src/storage/mmap.rs:26-98).
+header (/root/reference/src/storage/mmap.rs:26-98); staging file of the Python binding —
+[u64 n][u64 d][f32 ...], grown by appending (/root/reference/src/python_bindings.rs:313-430).
 """
 from __future__ import annotations
 
@@ -49,6 +50,14 @@ def write_fvecs(path: str, x: np.ndarray) -> None:
     out.tofile(path)
 
 
+def write_ivecs(path: str, x: np.ndarray) -> None:
+    x = np.ascontiguousarray(x, dtype="<i4")
+    out = np.empty((x.shape[0], x.shape[1] + 1), dtype="<i4")
+    out[:, 0] = x.shape[1]
+    out[:, 1:] = x
+    out.tofile(path)
+
+
 def read_generator_bin(path: str) -> np.ndarray:
     with open(path, "rb") as f:
         n, d = np.fromfile(f, dtype="<u4", count=2)
@@ -66,6 +75,47 @@ def read_raw_vectors(path: str, dim: int, count: int) -> np.ndarray:
     if os.path.getsize(path) != count * dim * 4:
         raise ValueError(f"File size mismatch: expected {count * dim * 4} bytes, got {os.path.getsize(path)}")
     return np.memmap(path, dtype="<f4", mode="r", shape=(count, dim))
+
+
+def append_staging(path: str, new_rows: np.ndarray, dim: int) -> int:
+    """save_vectors_to_staging (python_bindings.rs:313-382): the first call creates the file with
+    the header [u64 count = 0][u64 dim]; every call appends its rows as little-endian f32 and then
+    rewrites the count at offset 0. Returns the count now in the header."""
+    new_rows = np.ascontiguousarray(new_rows, dtype="<f4").reshape(-1, dim)
+    if os.path.exists(path):
+        with open(path, "rb") as f:
+            before, have_dim = (int(v) for v in np.fromfile(f, dtype="<u8", count=2))
+        if have_dim != dim:
+            raise ValueError(f"Dimension mismatch: expected {dim}, got {have_dim}")
+    else:
+        before = 0
+        with open(path, "wb") as f:
+            np.asarray([0, dim], dtype="<u8").tofile(f)
+    with open(path, "r+b") as f:
+        f.seek(0, os.SEEK_END)
+        new_rows.tofile(f)
+        f.seek(0)
+        np.asarray([before + new_rows.shape[0]], dtype="<u8").tofile(f)
+    return before + new_rows.shape[0]
+
+
+def read_staging(path: str, dim: int) -> np.ndarray:
+    """load_vectors_from_staging (python_bindings.rs:385-430): no file -> no vectors; a header whose
+    dimension differs from `dim` is an error; a file shorter than its header promises is an error
+    (read_exact fails there)."""
+    if not os.path.exists(path):
+        return np.zeros((0, dim), dtype=np.float32)
+    with open(path, "rb") as f:
+        head = np.fromfile(f, dtype="<u8", count=2)
+        if head.size != 2:
+            raise ValueError("Failed to read header")
+        n, d = int(head[0]), int(head[1])
+        if d != dim:
+            raise ValueError(f"Dimension mismatch: expected {dim}, got {d}")
+        body = np.fromfile(f, dtype="<f4", count=n * d)
+    if body.size != n * d:
+        raise ValueError("Failed to read vector data")
+    return body.reshape(n, d)
 
 
 def synthetic_mixture(n: int, dim: int, seed: int, device="cpu", n_top: int = 100, n_sub: int = 10,
