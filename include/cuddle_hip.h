@@ -281,6 +281,43 @@ cuddle_status cuddle_kmeans_assign(const float *d_vectors, uint64_t n, const flo
                                    float *d_dist, uint64_t *out_fallbacks, int device_id,
                                    void *stream);
 
+/* KMeans::update_centroids (src/clustering/kmeans.rs:163-215): d_centroids[c] = the mean of the vectors
+ * with d_assign[v] == c, d_counts[c] = how many there are. The sum is formed as the reference forms it:
+ * per chunk of 2048 consecutive vectors one sequential f32 accumulation in vector order (:170-183), the
+ * chunks' sums merged in chunk order (rayon's reduce, :187-199, keeps the order and leaves the grouping
+ * open; this merges from the left), then divided by the count as f32 (:209-213). The row of a cluster
+ * without vectors is left untouched: the reference re-seeds it with a randomly drawn vector (:217-223),
+ * which is the caller's draw to make. Assignments >= k are ignored. Device pointers: d_vectors [n][dim],
+ * d_assign [n], d_centroids [k][dim], d_counts [k]. dim <= 11264. Allocates its workspace per call and
+ * returns after the work on `stream` has finished. */
+cuddle_status cuddle_kmeans_update(const float *d_vectors, uint64_t n, uint32_t dim, const uint32_t *d_assign,
+                                   uint32_t k, float *d_centroids, uint32_t *d_counts, int device_id,
+                                   void *stream);
+
+/* KMeans::init_plusplus (src/clustering/kmeans.rs:36-88) with the reference's random draws passed in:
+ * `first` = the index vectors.choose() returned (:49), uniforms[j - 1] (host, k - 1 values in [0, 1)) =
+ * rand::random::<f32>() of round j (:68). Every round evaluates distance(v, newest centroid) for all
+ * vectors on the device and keeps the running minimum (:55-64); the sum of the squared distances and
+ * the walk that picks the next centroid (:67-77) are sequential single-precision chains and run on the
+ * host, over the weights copied back each round. d_centroids [k][dim] (device) receives the chosen
+ * rows, chosen [k] (host, may be NULL) their indices. Returns when done. */
+cuddle_status cuddle_kmeanspp_init(const float *d_vectors, uint64_t n, uint32_t dim, uint32_t k,
+                                   uint32_t metric, uint64_t first, const float *uniforms,
+                                   float *d_centroids, uint64_t *chosen, int device_id, void *stream);
+
+/* BinaryQuantizer::quantize (src/quantization/binary.rs:144-159) for n device-resident vectors:
+ * d_codes [n][ceil(dim/64)]. Enqueued on `stream`. (cuddle_binary_quantize is the host-pointer form.) */
+cuddle_status cuddle_binary_encode_device(const float *d_vectors, uint64_t n, uint32_t dim, float threshold,
+                                          uint64_t *d_codes, int device_id, void *stream);
+
+/* RaBitQQuantizer::quantize / quantize_batch (src/quantization/rabitq.rs:114-179) for n device-resident
+ * vectors: d_codes [n][ceil(dim/32)], d_norm [n], d_ip_oo [n], every sum in the reference's order.
+ * d_rot_t [dim][dim] = rotation_matrix_t (:20) on the device. Returns after the work on `stream` has
+ * finished. */
+cuddle_status cuddle_rabitq_encode_device(const float *d_rot_t, uint32_t dim, const float *d_vectors,
+                                          uint64_t n, uint32_t *d_codes, float *d_norm, float *d_ip_oo,
+                                          int device_id, void *stream);
+
 /* Diagnostic of the matrix-core routing filter (no counterpart in the reference, whose routing
  * at hierarchical.rs:355-391 evaluates every distance exactly; here a level as wide as a whole
  * frontier is first ranked by approximate distances, and the selection is accepted only where an

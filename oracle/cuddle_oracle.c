@@ -168,6 +168,86 @@ void orc_kmeans_assign(const float *vectors, uint64_t n, const float *centroids,
     }
 }
 
+/* KMeans::update_centroids, src/clustering/kmeans.rs:163-215. The reference sums each cluster's
+ * vectors per chunk of 2048 consecutive vectors (one sequential f32 accumulation per chunk, cluster
+ * and component, :178-183) and merges the chunks' partial sums with rayon's reduce (:187-199), which
+ * keeps the chunks in order but leaves the grouping of the additions to the scheduler; this
+ * restatement merges them from the left, one of the groupings the reference can produce. A chunk in
+ * which a cluster has no vector contributes +0.0, which changes nothing. mean = sum / (count as f32)
+ * (:209-213); the row of a cluster without vectors is left as it was (the reference replaces it with
+ * a randomly drawn vector, :217-223: the caller's business here). counts[c] = vectors of cluster c. */
+void orc_kmeans_update(const float *vectors, uint64_t n, uint32_t dim, const uint32_t *assign, uint32_t k,
+                       float *centroids, uint32_t *counts) {
+    float *total = (float *)calloc((size_t)k * dim, sizeof(float));
+    float *part = (float *)malloc((size_t)k * dim * sizeof(float));
+    unsigned char *touched = (unsigned char *)malloc(k);
+    for (uint32_t c = 0; c < k; ++c) counts[c] = 0;
+    for (uint64_t base = 0; base < n; base += 2048) {
+        const uint64_t end = base + 2048 < n ? base + 2048 : n;
+        memset(touched, 0, k);
+        for (uint64_t v = base; v < end; ++v) {
+            const uint32_t c = assign[v];
+            float *p = part + (size_t)c * dim;
+            if (!touched[c]) {
+                touched[c] = 1;
+                for (uint32_t i = 0; i < dim; ++i) p[i] = 0.0f;
+            }
+            const float *x = vectors + v * dim;
+            for (uint32_t i = 0; i < dim; ++i) p[i] += x[i];
+            counts[c] += 1;
+        }
+        for (uint32_t c = 0; c < k; ++c)
+            if (touched[c]) {
+                float *t = total + (size_t)c * dim;
+                const float *p = part + (size_t)c * dim;
+                for (uint32_t i = 0; i < dim; ++i) t[i] += p[i];
+            }
+    }
+    for (uint32_t c = 0; c < k; ++c)
+        if (counts[c]) {
+            const float cf = (float)counts[c];
+            for (uint32_t i = 0; i < dim; ++i) centroids[(size_t)c * dim + i] = total[(size_t)c * dim + i] / cf;
+        }
+    free(total);
+    free(part);
+    free(touched);
+}
+
+/* KMeans::init_plusplus, src/clustering/kmeans.rs:36-88, with the reference's random draws handed in:
+ * `first` = the index vectors.choose() picked (:49), uniforms[j - 1] = the value of rand::random::<f32>()
+ * in round j (:68). Per round: every vector's distance to its nearest centroid so far (min over
+ * distance(v, c, metric), :55-64), total = the sequential f32 sum of the squares (:67), target = u * total,
+ * then the first index at which the running target - d*d drops to <= 0 (:70-77; index 0 when it never
+ * does). chosen[j] = index of centroid j; centroids [k][dim] receives the rows. */
+void orc_kmeanspp_init(const float *vectors, uint64_t n, uint32_t dim, uint32_t k, int metric, uint64_t first,
+                       const float *uniforms, float *centroids, uint64_t *chosen) {
+    float *mind = (float *)malloc(n * sizeof(float));
+    chosen[0] = first;
+    memcpy(centroids, vectors + first * dim, dim * sizeof(float));
+    for (uint32_t j = 1; j < k; ++j) {
+        const float *cn = centroids + (size_t)(j - 1) * dim;
+#pragma omp parallel for schedule(static)
+        for (int64_t v = 0; v < (int64_t)n; ++v) {
+            const float d = orc_distance(vectors + (uint64_t)v * dim, cn, dim, metric);
+            if (j == 1 || d < mind[v]) mind[v] = d;
+        }
+        float total = 0.0f;
+        for (uint64_t v = 0; v < n; ++v) total += mind[v] * mind[v];
+        float target = uniforms[j - 1] * total;
+        uint64_t idx = 0;
+        for (uint64_t v = 0; v < n; ++v) {
+            target -= mind[v] * mind[v];
+            if (target <= 0.0f) {
+                idx = v;
+                break;
+            }
+        }
+        chosen[j] = idx;
+        memcpy(centroids + (size_t)j * dim, vectors + idx * dim, dim * sizeof(float));
+    }
+    free(mind);
+}
+
 /* ---------------------------------------------------------------------------------------- */
 /* src/quantization/binary.rs                                                                */
 /* ---------------------------------------------------------------------------------------- */

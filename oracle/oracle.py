@@ -58,6 +58,8 @@ def lib() -> C.CDLL:
             "orc_distance": (f32, [vp, vp, C.c_size_t, C.c_int]),
             "orc_distance_pairs": (None, [vp, vp, u64, u32, C.c_int, vp]),
             "orc_kmeans_assign": (None, [vp, u64, vp, u32, u32, C.c_int, vp, vp]),
+            "orc_kmeans_update": (None, [vp, u64, u32, vp, u32, vp, vp]),
+            "orc_kmeanspp_init": (None, [vp, u64, u32, u32, C.c_int, u64, vp, vp, vp]),
             "orc_binary_quantize": (None, [vp, u64, u32, f32, vp]),
             "orc_binary_threshold": (f32, [vp, u64, u32]),
             "orc_hamming": (u32, [vp, vp, u32]),
@@ -125,6 +127,28 @@ def kmeans_assign(vectors, centroids, metric: int):
     dist = np.zeros(v.shape[0], dtype=np.float32)
     lib().orc_kmeans_assign(_p(v), v.shape[0], _p(c), c.shape[0], v.shape[1], metric, _p(assign), _p(dist))
     return assign, dist
+
+
+def kmeans_update(vectors, assign, k: int, centroids=None):
+    """KMeans::update_centroids (kmeans.rs:163-215): (centroids [k, d], counts [k]); rows of empty
+    clusters keep the value `centroids` had (zeros when not given)."""
+    v = _f32(vectors)
+    a = np.ascontiguousarray(assign, dtype=np.uint32)
+    c = np.zeros((k, v.shape[1]), dtype=np.float32) if centroids is None else _f32(centroids).copy()
+    counts = np.zeros(k, dtype=np.uint32)
+    lib().orc_kmeans_update(_p(v), v.shape[0], v.shape[1], _p(a), k, _p(c), _p(counts))
+    return c, counts
+
+
+def kmeanspp_init(vectors, k: int, metric: int, first: int, uniforms):
+    """KMeans::init_plusplus (kmeans.rs:36-88) with the random draws given: (centroids [k, d], chosen [k])."""
+    v = _f32(vectors)
+    u = _f32(uniforms)
+    assert u.size >= k - 1
+    c = np.zeros((k, v.shape[1]), dtype=np.float32)
+    chosen = np.zeros(k, dtype=np.uint64)
+    lib().orc_kmeanspp_init(_p(v), v.shape[0], v.shape[1], k, metric, first, _p(u), _p(c), _p(chosen))
+    return c, chosen
 
 
 def binary_quantize(v, threshold: float) -> np.ndarray:

@@ -1,0 +1,112 @@
+"""GPU: the index-build kernels behind the C ABI against the CPU oracle, bit for bit — centroid update
+(src/clustering/kmeans.rs:163-215), k-means++ seeding with the random draws handed in (:36-88), binary
+and RaBitQ batch encoding (src/quantization/binary.rs:144-159, rabitq.rs:114-179)."""
+import numpy as np
+import pytest
+import torch
+
+from vectordb_amd import _ffi
+from vectordb_amd import builder as B
+
+from helpers import clustered
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import oracle as orc
+    return orc
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("n,d,k", [(5000, 16, 7), (20000, 128, 100), (4100, 960, 40), (6000, 37, 3000), (2048, 64, 1), (1, 8, 3)])
+def test_kmeans_update_matches_oracle(gpu, n, d, k):
+    orc = _oracle()
+    rng = np.random.default_rng(n + d + k)
+    x = (rng.standard_normal((n, d)) * 3 + 1).astype(np.float32)
+    assign = rng.integers(0, k, n).astype(np.uint32)
+    if k > 4:
+        assign[assign == 2] = 3  # an empty cluster: its row must keep the caller's value
+    prev = rng.standard_normal((k, d)).astype(np.float32)
+    want_c, want_n = orc.kmeans_update(x, assign, k, prev)
+    dev = torch.device("cuda", gpu)
+    got_c, got_n = B.kmeans_update(torch.from_numpy(x).to(dev), torch.from_numpy(assign.astype(np.int32)).to(dev), k,
+                                   torch.from_numpy(prev).to(dev))
+    assert np.array_equal(got_n.cpu().numpy().astype(np.uint32), want_n)
+    assert np.array_equal(_bits(got_c.cpu().numpy()), _bits(want_c))
+    if k > 4:
+        assert want_n[2] == 0 and np.array_equal(got_c[2].cpu().numpy(), prev[2])
+
+
+def test_kmeans_update_sum_order_is_the_chunked_one(gpu):
+    """Values chosen so that the order of the additions shows: 2^24 absorbs a following 1.0 but not a 1.0 + 1.0
+    formed first. One cluster, vectors 0..2047 in the first chunk, the rest in the second."""
+    orc = _oracle()
+    n = 2048 + 3
+    x = np.ones((n, 1), dtype=np.float32)
+    x[0, 0] = 2.0 ** 24
+    assign = np.zeros(n, dtype=np.uint32)
+    want_c, _ = orc.kmeans_update(x, assign, 1)
+    # first chunk: 2^24 + 1 + 1 ... stays 2^24; second chunk: 1 + 1 + 1 = 3; 2^24 + 3 rounds to 2^24 + 4
+    assert want_c[0, 0] == np.float32((2.0 ** 24 + 4.0)) / np.float32(n)
+    dev = torch.device("cuda", gpu)
+    got_c, got_n = B.kmeans_update(torch.from_numpy(x).to(dev), torch.from_numpy(assign.astype(np.int32)).to(dev), 1)
+    assert int(got_n[0]) == n and np.array_equal(_bits(got_c.cpu().numpy()), _bits(want_c))
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+@pytest.mark.parametrize("n,d,k", [(3000, 24, 12), (10000, 128, 30), (700, 130, 5)])
+def test_kmeanspp_init_matches_oracle(gpu, metric, n, d, k):
+    orc = _oracle()
+    rng = np.random.default_rng(d + k)
+    x = clustered(n, d, 20, d, sigma=0.3)
+    if metric == "dot":
+        x = np.abs(x) + 0.1
+    u = rng.random(k - 1).astype(np.float32)
+    first = int(rng.integers(0, n))
+    want_c, want_i = orc.kmeanspp_init(x, k, B.metric_id(metric), first, u)
+    got_c, got_i = B.kmeanspp_init(torch.from_numpy(x).to(torch.device("cuda", gpu)), k, metric, first, u)
+    assert np.array_equal(got_i, want_i)
+    assert np.array_equal(_bits(got_c.cpu().numpy()), _bits(want_c))
+    assert got_i[0] == first and len(set(got_i.tolist())) > 1
+
+
+def test_kmeanspp_argument_checks(gpu):
+    x = torch.zeros((4, 8), device=torch.device("cuda", gpu))
+    with pytest.raises(_ffi.CuddleError):
+        B.kmeanspp_init(x, 5, "l2", 0, np.zeros(4, np.float32))  # k > n (kmeans.rs:42)
+    with pytest.raises(_ffi.CuddleError):
+        B.kmeanspp_init(x, 2, "l2", 9, np.zeros(1, np.float32))  # first out of range
+    c, i = B.kmeanspp_init(x, 3, "l2", 1, np.array([0.5, 0.5], np.float32))  # all distances zero: index 0 is chosen (:70-77)
+    assert i.tolist() == [1, 0, 0]
+
+
+@pytest.mark.parametrize("d", [64, 100, 960, 128])
+def test_binary_encode_device_matches_oracle(gpu, d):
+    orc = _oracle()
+    rng = np.random.default_rng(d)
+    x = rng.standard_normal((3001, d)).astype(np.float32)
+    x[5] = 0.25  # values equal to the threshold are 0 bits (strict >)
+    want = orc.binary_quantize(x, 0.25)
+    got = B.binary_encode_device(torch.from_numpy(x).to(torch.device("cuda", gpu)), 0.25)
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), want)
+
+
+@pytest.mark.parametrize("d,n", [(64, 1000), (96, 777), (768, 260), (100, 513), (1030, 40)])
+def test_rabitq_encode_device_matches_oracle(gpu, d, n):
+    orc = _oracle()
+    rng = np.random.default_rng(d * 7 + n)
+    x = (rng.standard_normal((n, d)) * rng.uniform(0.01, 30.0, (n, 1))).astype(np.float32)
+    x[3] = 0.0          # zero vector: code 0, norm 0, <o_bar, o> = 1 (rabitq.rs:121-127)
+    x[4] = 1e-12        # below the 1e-10 norm limit as well
+    rot = B.make_rotation(d, 11)
+    want_codes, want_norm, want_ip = orc.rabitq_quantize(rot, x)
+    dev = torch.device("cuda", gpu)
+    codes, norm, ip = B.rabitq_encode_device(torch.from_numpy(x).to(dev), torch.from_numpy(rot).to(dev))
+    assert np.array_equal(codes.cpu().numpy().view(np.uint32), want_codes)
+    assert np.array_equal(_bits(norm.cpu().numpy()), _bits(want_norm))
+    assert np.array_equal(_bits(ip.cpu().numpy()), _bits(want_ip))
+    assert not codes[3].any() and float(norm[3]) == 0.0 and float(ip[3]) == 1.0

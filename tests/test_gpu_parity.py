@@ -138,6 +138,31 @@ def test_grouped_routing_is_exact(gpu, metric, d):
     _compare_full(fi, dev, q[:30], 10, 8, 5, _ffi.SEARCH_ROUTE_GROUPED | _ffi.SEARCH_STATS_VARIANT)
 
 
+def test_grouped_routing_proof_failures_take_the_exact_path(gpu, monkeypatch):
+    """With no spare candidates (CUDDLE_ROUTE_MARGIN=0) the exactness proof of the grouped level fails for
+    most queries. Their frontiers exist only as segment tables at that point and must be written out for
+    the exact kernels; the leaf lists must still be the all-exact path's and the oracle's."""
+    orc = _oracle()
+    x = clustered(40000, 64, 200, 13, sigma=0.3)
+    from vectordb_amd.builder import build_index
+    fi = build_index(x, 30, 20, "l2", 6, seed=5)
+    assert fi.n_levels() >= 3
+    monkeypatch.setenv("CUDDLE_ROUTE_MARGIN", "0")
+    dev = DeviceIndex(fi, gpu)
+    q = queries_like(x, 150, 9, noise=0.1)
+    lv_g, lc_g = dev.route_batch(q, 8, _ffi.SEARCH_ROUTE_GROUPED)
+    lv_e, lc_e = dev.route_batch(q, 8, _ffi.SEARCH_ROUTE_EXACT_ONLY)
+    assert np.array_equal(lc_g, lc_e)
+    for i in range(q.shape[0]):
+        assert np.array_equal(lv_g[i, :lc_g[i]], lv_e[i, :lc_e[i]]), i
+    ids, dist, cnt, st = dev.search_batch(q, 10, 8, 5, _ffi.SEARCH_ROUTE_GROUPED, want_stats=True)
+    assert st["route_fallbacks"] > q.shape[0] // 2, st
+    oi = orc.OracleIndex(fi)
+    for i in range(0, q.shape[0], 5):
+        t = oi.search(q[i], 10, 8, 5, trace=True)
+        assert np.array_equal(ids[i, :cnt[i]], t["ids"][:t["count"]]), i
+
+
 @pytest.mark.parametrize("metric,d", [("l2", 64), ("cosine", 96), ("dot", 40)])
 def test_rabitq_search_matches_oracle(gpu, metric, d):
     """RaBitQ phase 1: rotation, estimates, f32 selection, rerank, top-k — all bit-exact."""

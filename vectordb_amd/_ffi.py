@@ -120,6 +120,10 @@ SIGNATURES = {
     "cuddle_route_batch_device": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _u32, _vp, _vp]),
     "cuddle_shard_scan_leaves": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp, _vp]),
     "cuddle_kmeans_assign": (_int, [_vp, _u64, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _int, _vp]),
+    "cuddle_kmeans_update": (_int, [_vp, _u64, _u32, _vp, _u32, _vp, _vp, _int, _vp]),
+    "cuddle_kmeanspp_init": (_int, [_vp, _u64, _u32, _u32, _u32, _u64, _vp, _vp, _vp, _int, _vp]),
+    "cuddle_binary_encode_device": (_int, [_vp, _u64, _u32, C.c_float, _vp, _int, _vp]),
+    "cuddle_rabitq_encode_device": (_int, [_vp, _u32, _vp, _u64, _vp, _vp, _vp, _int, _vp]),
     "cuddle_scan_batch": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _vp, _vp, _vp, _u32, _vp]),
     "cuddle_search_leaves_batch": (
         _int,

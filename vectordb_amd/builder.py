@@ -61,6 +61,68 @@ def kmeans_assign(x: torch.Tensor, c: torch.Tensor, metric, stream=None):
     return assign, dist, int(fb[0])
 
 
+def _stream(t: torch.Tensor, stream):
+    return (stream if stream is not None else torch.cuda.current_stream(t.device)).cuda_stream
+
+
+def kmeans_update(x: torch.Tensor, assign: torch.Tensor, k: int, centroids: Optional[torch.Tensor] = None, stream=None):
+    """KMeans::update_centroids (kmeans.rs:163-215) on the GPU (cuddle_kmeans_update): (centroids [k, d]
+    f32, counts [k] int32). Rows of empty clusters keep what `centroids` held (zeros when not given):
+    re-seeding them (:217-223) is a random draw and stays with the caller."""
+    if not x.is_cuda:
+        raise ValueError("kmeans_update runs on the GPU: pass CUDA tensors")
+    x = x.contiguous().float()
+    a = assign.to(torch.int32).contiguous()
+    cent = torch.zeros((k, x.shape[1]), dtype=torch.float32, device=x.device) if centroids is None else centroids.contiguous().float().clone()
+    counts = torch.empty(k, dtype=torch.int32, device=x.device)
+    _ffi.check(_ffi.lib().cuddle_kmeans_update(x.data_ptr(), x.shape[0], x.shape[1], a.data_ptr(), k, cent.data_ptr(),
+                                               counts.data_ptr(), x.device.index or 0, _stream(x, stream)))
+    return cent, counts
+
+
+def kmeanspp_init(x: torch.Tensor, k: int, metric, first: int, uniforms, stream=None):
+    """KMeans::init_plusplus (kmeans.rs:36-88) with the random draws given (cuddle_kmeanspp_init):
+    (centroids [k, d] CUDA f32, chosen [k] uint64 numpy)."""
+    if not x.is_cuda:
+        raise ValueError("kmeanspp_init runs on the GPU: pass a CUDA tensor")
+    x = x.contiguous().float()
+    u = np.ascontiguousarray(uniforms, dtype=np.float32)
+    if u.size < k - 1:
+        raise ValueError("need k - 1 uniform draws")
+    cent = torch.empty((k, x.shape[1]), dtype=torch.float32, device=x.device)
+    chosen = np.zeros(k, dtype=np.uint64)
+    _ffi.check(_ffi.lib().cuddle_kmeanspp_init(x.data_ptr(), x.shape[0], x.shape[1], k, metric_id(metric), int(first), _ffi.ptr(u),
+                                               cent.data_ptr(), _ffi.ptr(chosen), x.device.index or 0, _stream(x, stream)))
+    return cent, chosen
+
+
+def binary_encode_device(x: torch.Tensor, threshold: float, stream=None) -> torch.Tensor:
+    """BinaryQuantizer::quantize (binary.rs:144-159) for CUDA rows: codes as int64 [n, ceil(d/64)] (the u64 bit patterns)."""
+    if not x.is_cuda:
+        raise ValueError("binary_encode_device runs on the GPU: pass a CUDA tensor")
+    x = x.contiguous().float()
+    codes = torch.empty((x.shape[0], (x.shape[1] + 63) // 64), dtype=torch.int64, device=x.device)
+    _ffi.check(_ffi.lib().cuddle_binary_encode_device(x.data_ptr(), x.shape[0], x.shape[1], float(threshold), codes.data_ptr(),
+                                                      x.device.index or 0, _stream(x, stream)))
+    return codes
+
+
+def rabitq_encode_device(x: torch.Tensor, rot_t: torch.Tensor, stream=None):
+    """RaBitQQuantizer::quantize_batch (rabitq.rs:114-179) for CUDA rows, sums in the reference's order:
+    (codes int32 [n, ceil(d/32)] holding the u32 bit patterns, norms f32 [n], ip_oo f32 [n])."""
+    if not (x.is_cuda and rot_t.is_cuda):
+        raise ValueError("rabitq_encode_device runs on the GPU: pass CUDA tensors")
+    x = x.contiguous().float()
+    r = rot_t.contiguous().float()
+    n, d = x.shape
+    codes = torch.empty((n, (d + 31) // 32), dtype=torch.int32, device=x.device)
+    norms = torch.empty(n, dtype=torch.float32, device=x.device)
+    ipoo = torch.empty(n, dtype=torch.float32, device=x.device)
+    _ffi.check(_ffi.lib().cuddle_rabitq_encode_device(r.data_ptr(), d, x.data_ptr(), n, codes.data_ptr(), norms.data_ptr(),
+                                                      ipoo.data_ptr(), x.device.index or 0, _stream(x, stream)))
+    return codes, norms, ipoo
+
+
 def _assign(x: torch.Tensor, c: torch.Tensor, metric: int, chunk: int = 262144) -> torch.Tensor:
     if x.is_cuda:  # native exact assignment; a missing library is an error, not a fallback
         return kmeans_assign(x, c, metric)[0].long()
@@ -77,6 +139,8 @@ def kmeans_fit(x: torch.Tensor, k: int, metric: int, max_iterations: int, gen: t
     re-seeded with a random point (:217-223). Returns (centroids [k,d], assignment [n])."""
     n = x.shape[0]
     dev = x.device
+    if x.is_cuda:
+        return _kmeans_fit_native(x, k, metric, max_iterations, gen)
     first = int(torch.randint(0, n, (1,), generator=gen).item())
     cent = torch.empty((k, x.shape[1]), dtype=x.dtype, device=dev)
     cent[0] = x[first]
@@ -108,6 +172,28 @@ def kmeans_fit(x: torch.Tensor, k: int, metric: int, max_iterations: int, gen: t
             break
         prev = assign.clone()
     return cent, assign
+
+
+def _kmeans_fit_native(x: torch.Tensor, k: int, metric: int, max_iterations: int, gen: torch.Generator):
+    """kmeans_fit for CUDA tensors through the library's build entry points, each of which follows the
+    reference's arithmetic: seeding (cuddle_kmeanspp_init), assignment (cuddle_kmeans_assign), centroid
+    update (cuddle_kmeans_update). Only the random draws are made here."""
+    n = x.shape[0]
+    first = int(torch.randint(0, n, (1,), generator=gen).item())
+    u = torch.rand((max(k - 1, 1),), generator=gen).numpy()
+    cent, _ = kmeanspp_init(x, k, metric, first, u)
+    assign = kmeans_assign(x, cent, metric)[0]
+    prev = assign.clone()
+    for _ in range(min(max_iterations, 12)):
+        cent, counts = kmeans_update(x, assign, k, cent)
+        for e in torch.nonzero(counts == 0).flatten().tolist():  # kmeans.rs:217-223
+            cent[e] = x[int(torch.randint(0, n, (1,), generator=gen).item())]
+        assign = kmeans_assign(x, cent, metric)[0]
+        changed = int((assign != prev).sum().item())
+        if changed / n < 0.02:
+            break
+        prev = assign.clone()
+    return cent, assign.long()
 
 
 class _Tree:
@@ -274,11 +360,18 @@ def build_index(vectors, branching_factor: int = 100, target_leaf_size: int = 10
             fi.threshold = float(x.double().mean().item())
         else:
             fi.threshold = float(threshold)
-        fi.codes = pack_binary_codes_torch(x[ids_t], fi.threshold) if dev.type != "cpu" else pack_binary_codes(vec_lc, fi.threshold)
+        if dev.type == "cuda":
+            fi.codes = binary_encode_device(x[ids_t], fi.threshold).cpu().numpy().view(np.uint64)
+        else:
+            fi.codes = pack_binary_codes(vec_lc, fi.threshold)
     elif code_kind == "rabitq":
         rot = make_rotation(d, seed + 7919)
         fi.rabitq_rot_t = rot
-        fi.rabitq_codes, fi.rabitq_norm, fi.rabitq_ip_oo = rabitq_encode(x[ids_t], torch.from_numpy(rot).to(dev))
+        if dev.type == "cuda":
+            c, nr, ip = rabitq_encode_device(x[ids_t], torch.from_numpy(rot).to(dev))
+            fi.rabitq_codes, fi.rabitq_norm, fi.rabitq_ip_oo = c.cpu().numpy().view(np.uint32), nr.cpu().numpy(), ip.cpu().numpy()
+        else:
+            fi.rabitq_codes, fi.rabitq_norm, fi.rabitq_ip_oo = rabitq_encode(x[ids_t], torch.from_numpy(rot))
     else:
         raise ValueError(f"unknown code_kind {code_kind!r}")
     return fi.normalised()

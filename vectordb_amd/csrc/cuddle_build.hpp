@@ -1,6 +1,7 @@
 // cuddle_build.hpp — index-build side of the path: exact nearest-centroid assignment, the inner
 // step of k-means (reference: src/clustering/kmeans.rs:136-160, KMeans::assign; also
-// nearest_centroid, :229-236).
+// nearest_centroid, :229-236); the centroid update (:163-215); the distance step of k-means++
+// seeding (:55-64); RaBitQ encoding of the stored vectors (src/quantization/rabitq.rs:114-171).
 //
 // The reference evaluates distance(v, c, metric) for every (vector, centroid) pair and keeps the
 // first minimum (Iterator::min_by returns the first of equal minima). Here the n x k distance matrix
@@ -154,6 +155,199 @@ assign_finish_kernel(const float *vectors, const float *centroids, uint32_t M, u
         assign[row] = best_i;
         dist[row] = best_d;
         if (full) atomicAdd(fallbacks, full);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// centroid update (KMeans::update_centroids, kmeans.rs:163-215)
+// ---------------------------------------------------------------------------------------------
+// The reference adds a cluster's vectors up per chunk of 2048 consecutive vectors, one sequential f32
+// accumulation per (chunk, cluster, component), and merges the chunks' sums in chunk order; here
+// kmeans_partial_kernel produces the per-chunk sums in exactly that order and kmeans_fold_kernel merges
+// them from the left (a chunk without vectors of a cluster contributes +0.0, which changes nothing).
+constexpr uint32_t kUpdateChunk = 2048;      // vectors per partial sum (kmeans.rs:170)
+constexpr uint32_t kUpdateAccFloats = 11264; // accumulator floats a block keeps in LDS (44 KB + the 8 KB list: three blocks per CU)
+
+__global__ void __launch_bounds__(256)
+kmeans_count_kernel(const uint32_t *assign, uint64_t n, uint32_t k, uint32_t *counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = assign[i];
+    if (c < k) atomicAdd(&counts[c], 1u);
+}
+
+// Block (chunk, cluster range r) sums the chunk's vectors of clusters [r * kr, (r + 1) * kr) in vector
+// order: thread t owns components t, t + blockDim, ...; the accumulators of the range live in LDS.
+// part: [chunks of this launch][k][dim]. Vectors whose cluster id is not below k are ignored.
+// grid = (chunks, ceil(k / kr)), block = 64, 128 or 256 threads, dynamic LDS = kr * dim * 4 + 2048 * 4 bytes.
+__global__ void __launch_bounds__(256)
+kmeans_partial_kernel(const float *vectors, const uint32_t *assign, uint64_t n, uint32_t dim, uint32_t k, uint32_t kr,
+                      uint64_t first_chunk, float *part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *acc = reinterpret_cast<float *>(smem);                                  // [kr][dim]
+    uint32_t *list = reinterpret_cast<uint32_t *>(acc + (size_t)kr * dim);        // [2048] (position in chunk) << 16 | local cluster
+    __shared__ uint32_t wsum[4], s_n;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint64_t base = (first_chunk + blockIdx.x) * kUpdateChunk;
+    const uint32_t m = (uint32_t)min((uint64_t)kUpdateChunk, n - base);
+    const uint32_t c0 = blockIdx.y * kr, c1 = min(c0 + kr, k);
+    for (uint32_t i = tid; i < (c1 - c0) * dim; i += nt) acc[i] = 0.f;
+    // the chunk's vectors of this range, in vector order: thread t looks at positions [t * per, (t + 1) * per)
+    const uint32_t per = kUpdateChunk / nt;
+    uint32_t mine = 0;
+    for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t p = tid * per + j;
+        const uint32_t c = p < m ? assign[base + p] : 0xFFFFFFFFu;
+        mine += (c >= c0 && c < c1) ? 1u : 0u;
+    }
+    const uint32_t incl = wave_inclusive_sum(mine);
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t off = incl - mine;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) off += wsum[w];
+    if (tid == nt - 1) s_n = off + mine;
+    for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t p = tid * per + j;
+        const uint32_t c = p < m ? assign[base + p] : 0xFFFFFFFFu;
+        if (c >= c0 && c < c1) list[off++] = (p << 16) | (c - c0);
+    }
+    __syncthreads();
+    const uint32_t cnt = s_n;
+    const float *vb = vectors + base * dim;
+    for (uint32_t i = tid; i < dim; i += nt) {
+        uint32_t j = 0;
+        for (; j + 8 <= cnt; j += 8) { // eight rows in flight, then the eight additions in order
+            uint32_t e[8];
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) e[u] = list[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = vb[(uint64_t)(e[u] >> 16) * dim + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[(e[u] & 0xFFFFu) * dim + i] += x[u];
+        }
+        for (; j < cnt; ++j) {
+            const uint32_t e = list[j];
+            acc[(e & 0xFFFFu) * dim + i] += vb[(uint64_t)(e >> 16) * dim + i];
+        }
+    }
+    __syncthreads();
+    float *out = part + ((uint64_t)blockIdx.x * k + c0) * dim;
+    for (uint32_t i = tid; i < (c1 - c0) * dim; i += nt) out[i] = acc[i];
+}
+
+// total[c][i] += part[0][c][i], then part[1][c][i], ... (left to right); with `last`, the mean
+// total / (count as f32) goes to the centroid rows of the clusters that have vectors (kmeans.rs:204-215).
+__global__ void __launch_bounds__(256)
+kmeans_fold_kernel(const float *part, uint32_t chunks, uint32_t k, uint32_t dim, float *total, const uint32_t *counts,
+                   float *centroids, uint32_t last) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x, kd = (uint64_t)k * dim;
+    if (g >= kd) return;
+    float t = total[g];
+    uint32_t ch = 0;
+    for (; ch + 8 <= chunks; ch += 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = part[(uint64_t)(ch + u) * kd + g];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += x[u];
+    }
+    for (; ch < chunks; ++ch) t += part[(uint64_t)ch * kd + g];
+    total[g] = t;
+    if (last) {
+        const uint32_t cnt = counts[g / dim];
+        if (cnt) centroids[g] = t / (float)cnt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k-means++ seeding, the parallel half of a round (KMeans::init_plusplus, kmeans.rs:55-67)
+// ---------------------------------------------------------------------------------------------
+// mind[v] = min(mind[v], distance(v, newest centroid)) (first round: the distance itself; the minimum
+// over the centroids chosen so far is the same value whichever order they are visited in), and
+// w[v] = mind[v] * mind[v], the weight the reference samples with. One 4-lane group per vector.
+__global__ void __launch_bounds__(256)
+kmeanspp_round_kernel(const float *vectors, uint64_t n, uint32_t dim, uint32_t metric, const float *centroid, float *mind,
+                      float *w, uint32_t first_round) {
+    const uint64_t v = (uint64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const uint32_t sub = threadIdx.x & 3;
+    const bool act = v < n;
+    const uint64_t vv = act ? v : n - 1; // idle groups shadow the last vector: the group reductions need all lanes
+    const float d = distance_group4(vectors + vv * dim, centroid, dim, metric, sub, (dim & 3) == 0);
+    if (act && sub == 0) {
+        const float m = first_round ? d : fminf(mind[v], d);
+        mind[v] = m;
+        w[v] = m * m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RaBitQ encoding (RaBitQQuantizer::quantize, rabitq.rs:114-171)
+// ---------------------------------------------------------------------------------------------
+// Per vector: norm = sqrt(sequential sum of squares) (:118); zero vectors (norm < 1e-10): code 0, norm 0,
+// <o_bar, o> = 1 (:121-127); otherwise o = v / norm, rotated_i = sum_j rot_t[i][j] * o[j] sequentially over
+// j (:138-140), bit i of word i / 32 = rotated_i >= 0 (:143-150), and <o_bar, o> = the sequential sum over i
+// of sign_i * rotated_i = |rotated_i| (:157-164). rot: the rotation in the layout transpose_square_kernel
+// makes (rot[j][i] = rot_t[i][j]), so that consecutive threads (consecutive i) read consecutive addresses.
+// A block encodes VB vectors: each rotation element is read once for all of them.
+// grid = ceil(n / VB), block 256, dynamic LDS = 2 * VB * dim * 4 bytes.
+template <int VB>
+__global__ void __launch_bounds__(256)
+rabitq_encode_kernel(const float *vectors, const float *rot, uint64_t n, uint32_t dim, uint32_t *codes, float *norms,
+                     float *ip_oo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *o = reinterpret_cast<float *>(smem); // [dim][VB]: component j of the block's normalised vectors side by side
+    float *mag = o + (size_t)VB * dim;          // [VB][dim]: |rotated|
+    __shared__ float s_norm[VB];
+    const uint64_t v0 = (uint64_t)blockIdx.x * VB;
+    const uint32_t tid = threadIdx.x, words = (dim + 31) / 32;
+    if (tid < VB) {
+        const uint64_t v = v0 + tid;
+        float sq = 0.f;
+        if (v < n)
+            for (uint32_t j = 0; j < dim; ++j) {
+                const float x = vectors[v * dim + j];
+                sq += x * x;
+            }
+        s_norm[tid] = sqrtf(sq);
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < VB * dim; t += 256) {
+        const uint32_t b = t / dim, j = t - b * dim;
+        const uint64_t v = v0 + b;
+        o[j * VB + b] = (v < n && s_norm[b] >= 1e-10f) ? vectors[v * dim + j] / s_norm[b] : 0.f;
+    }
+    __syncthreads();
+    const uint32_t dim64 = (dim + 63) & ~63u; // whole waves walk the output rows, so that the ballots below are complete
+    for (uint32_t i = tid; i < dim64; i += 256) {
+        float acc[VB];
+#pragma unroll
+        for (int b = 0; b < VB; ++b) acc[b] = 0.f;
+        if (i < dim)
+            for (uint32_t j = 0; j < dim; ++j) {
+                const float r = rot[(uint64_t)j * dim + i];
+#pragma unroll
+                for (int b = 0; b < VB; ++b) acc[b] += r * o[j * VB + b];
+            }
+#pragma unroll
+        for (int b = 0; b < VB; ++b) {
+            const uint64_t bits = __ballot(i < dim && acc[b] >= 0.0f);
+            const uint64_t v = v0 + b;
+            if ((tid & 31) == 0 && v < n && (i >> 5) < words)
+                codes[v * words + (i >> 5)] = s_norm[b] >= 1e-10f ? (uint32_t)(bits >> (tid & 32)) : 0u;
+            if (i < dim) mag[b * dim + i] = fabsf(acc[b]);
+        }
+    }
+    __syncthreads();
+    if (tid < VB) {
+        const uint64_t v = v0 + tid;
+        if (v < n) {
+            float ip = 0.f;
+            for (uint32_t i = 0; i < dim; ++i) ip += mag[tid * dim + i];
+            const bool zero = s_norm[tid] < 1e-10f;
+            norms[v] = zero ? 0.f : s_norm[tid];
+            ip_oo[v] = zero ? 1.f : ip;
+        }
     }
 }
 

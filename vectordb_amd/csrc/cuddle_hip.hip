@@ -150,6 +150,7 @@ struct Plan {
     uint16_t *gdist = nullptr;
     // (query, parent) pairs of the grouped routing level
     uint32_t *pair_info = nullptr, *pair_parent = nullptr, *pair_slot = nullptr, *pair_sorted = nullptr, *small_flag = nullptr;
+    uint32_t *seg[2] = {nullptr, nullptr}; // segment tables standing for per-query frontiers (see PairOut::seg), like frontier[]
     uint32_t *grp_cnt = nullptr, *grp_poff = nullptr, *grp_ioff = nullptr, *grp_fill = nullptr, *grp_item = nullptr;
     // leaf-sharded exact selection: threshold/budget per query, global order key of every selected candidate
     uint32_t *thr = nullptr;
@@ -658,6 +659,7 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     size_t o_thr = carve(qc * 8), o_sord = carve(qc * pl.sstride * 8), o_qn = carve(qc * 4);
     size_t o_lfc = carve(qc * ((size_t)ix->n_levels + 1) * 4);
     size_t o_ltb = carve(qc * 4 * ((size_t)pl.lstride + 4) * 4);
+    size_t o_sg0 = carve(qc * seg_stride(pl.probes) * 4), o_sg1 = carve(qc * seg_stride(pl.probes) * 4);
     if (!b) return off;
     pl.qcodes = (uint64_t *)(b + o_qcodes);
     pl.frontier[0] = (uint32_t *)(b + o_f0); pl.frontier[1] = (uint32_t *)(b + o_f1);
@@ -680,6 +682,7 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     pl.qnorm = (float *)(b + o_qn);
     pl.level_fc = (uint32_t *)(b + o_lfc);
     pl.leaf_tables = (uint32_t *)(b + o_ltb);
+    pl.seg[0] = (uint32_t *)(b + o_sg0); pl.seg[1] = (uint32_t *)(b + o_sg1);
     return off;
 }
 
@@ -881,6 +884,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
     int cur = 0;
     uint64_t fb = v.n_roots;
     bool grouped = false; // this level's distances come from the (query, parent) pairs of the level above
+    bool have_seg = false; // ... and the grouped queries' frontiers exist as segment tables only (pl.seg[cur])
+    static const bool no_filter = getenv("CUDDLE_GROUPED_EXACT") != nullptr; // tuning aid: exact distances for every pair
     for (uint32_t l = 0; l < ix->n_levels; ++l) {
         if (stats) // SearchStats::probes_per_level (hierarchical.rs:861): the frontier size of every query at this level
             HIP_TRY(hipMemcpyAsync(pl.level_fc + (size_t)l * pl.qc, pl.fcount[cur], (size_t)nq * 4, hipMemcpyDeviceToDevice, s));
@@ -906,7 +911,6 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         if (grouped) {
             // pairs recorded by the level above -> parent order -> one block per (parent, 8 queries)
             const uint32_t wprev = ix->level_width[l - 1], total = nq * pl.probes;
-            static const bool no_filter = getenv("CUDDLE_GROUPED_EXACT") != nullptr; // tuning aid: exact distances for every pair
             grouped_filter = !stats && g.n && bound <= 512 * 32 && !no_filter;
             const uint32_t nb = (wprev + kPairScanChunk - 1) / kPairScanChunk; // pl.grp_fill: 2 * nb block sums / offsets
             hipLaunchKernelGGL(pair_block_sums_kernel, dim3(nb), dim3(256), 0, s, pl.grp_cnt, wprev, pl.grp_fill, nb);
@@ -929,8 +933,10 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 CUDDLE_GROUPED_GEMM(64); // K chunk: 32 and 64 measured alike, 128 slower (fewer blocks in flight)
 #undef CUDDLE_GROUPED_GEMM
                 launch_prefilter(pl, nq, bound, kc, pl.fcount[cur], pl.small_flag, pl.rc_cnt, s);
-                hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
-                                   pl.frontier[cur], pl.rc_pos, pl.kc_cap, kc, pl.rc_dist, pl.qnorm, pl.fstride, pl.small_flag, pl.rc_cnt);
+                hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256),
+                                   (((size_t)v.dim + 3) & ~(size_t)3) * sizeof(float) + (have_seg ? seg_stride(pl.probes) * 4 : 0), s, v, dq,
+                                   pl.frontier[cur], pl.rc_pos, pl.kc_cap, kc, pl.rc_dist, pl.qnorm, pl.fstride, pl.small_flag, pl.rc_cnt,
+                                   have_seg ? pl.seg[cur] : nullptr, pl.probes);
                 grouped_finish = true; // launched below, once this level's PairOut is known
                 grouped_kc = kc;
                 only = pl.rflag;
@@ -945,7 +951,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         // Will the next level evaluate per-query frontiers wider than probes? Then this level's
         // expansion also records its (query, chosen node) pairs, grouped by node for that level.
         PairOut po;
-        bool group_next = false;
+        bool group_next = false, seg_next = false;
         if (l + 1 < ix->n_levels && !next_shared && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && pl.fstride <= (1u << kPairOffBits)) {
             // grouping has a fixed cost (pair sort, one block per 64 pairs): worth it when a query's
             // next frontier is expected to be wide, i.e. chosen nodes x mean fan-out of this level
@@ -956,14 +962,23 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 po.info = pl.pair_info; po.parent = pl.pair_parent; po.slot = pl.pair_slot; po.cnt = pl.grp_cnt; po.small = pl.small_flag;
                 po.pstride = pl.probes;
                 po.min_n = stats ? 0u : std::max<uint32_t>(pl.probes, 100);
+                // the next level will go through the contraction (the condition of grouped_filter there): its kernels
+                // need a frontier position's node for a few hundred positions per query, not the frontier itself
+                seg_next = !stats && ix->lvl[l + 1].n && bound_next <= 512 * 32 && !no_filter;
+                if (seg_next) po.seg = pl.seg[cur ^ 1];
                 HIP_TRY(hipMemsetAsync(pl.grp_cnt, 0, ((size_t)ix->level_width[l] + 1) * 4, s));
             }
         }
-        if (grouped_finish)
+        if (grouped_finish) {
             hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(grouped_kc), pl.probes), s,
                                v, pl.frontier[cur], bound, pl.rc_pos, pl.rc_dist, pl.kc_cap, grouped_kc, pl.rc_max, pl.qsq, g.max_sqn,
                                pl.probes, pl.frontier[cur ^ 1], pl.fstride, pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,
-                               pl.rflag, &ix->d_stats->fallbacks, po, pl.fcount[cur], pl.small_flag, pl.rc_cnt);
+                               pl.rflag, &ix->d_stats->fallbacks, po, pl.fcount[cur], pl.small_flag, pl.rc_cnt,
+                               have_seg ? pl.seg[cur] : nullptr);
+            if (have_seg) // queries that failed the proof go on through the kernels that walk whole frontiers
+                hipLaunchKernelGGL(route_materialise_kernel, dim3(nq), dim3(256), seg_stride(pl.probes) * 4, s, v, pl.seg[cur], pl.probes,
+                                   pl.rflag, pl.small_flag, pl.frontier[cur], pl.fstride, pl.fcount[cur]);
+        }
         const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound;
         if (use_gemm) {
             const uint32_t n = g.n, kc = std::min(n, pl.kc_cap);
@@ -1020,6 +1035,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         cur ^= 1;
         shared = next_shared;
         grouped = group_next;
+        have_seg = seg_next;
         fb = fb_next;
     }
     if (stats) // what is left below the last level: empty, the frontier on which the reference's loop ends
@@ -1576,6 +1592,124 @@ extern "C" cuddle_status cuddle_kmeans_assign(const float *d_vectors, uint64_t n
     HIP_TRY(hipMemcpyAsync(&fb, d_fb, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream)); // the workspace is freed on return
     if (out_fallbacks) *out_fallbacks = fb;
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_kmeans_update(const float *d_vectors, uint64_t n, uint32_t dim, const uint32_t *d_assign,
+                                              uint32_t k, float *d_centroids, uint32_t *d_counts, int device_id, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_centroids || !d_counts || ((!d_vectors || !d_assign) && n)) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    if (dim == 0 || k == 0) return fail(CUDDLE_ERR_BAD_ARG, "dim and k must be >= 1");
+    if (dim > kUpdateAccFloats) return fail(CUDDLE_ERR_UNSUPPORTED, "dim %u > %u", dim, kUpdateAccFloats);
+    if ((uint64_t)k * dim > (1ull << 31)) return fail(CUDDLE_ERR_UNSUPPORTED, "k * dim too large");
+    ST_TRY(use_device(device_id));
+    HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)k * 4, stream));
+    if (n == 0) return CUDDLE_OK;
+    const uint64_t kd = (uint64_t)k * dim, chunks = (n + kUpdateChunk - 1) / kUpdateChunk;
+    // chunks per pass: their partial sums ([chunks][k][dim] f32) stay within half a GiB (at least one chunk)
+    const uint64_t per_pass = std::max<uint64_t>(1, std::min<uint64_t>(chunks, (512ull << 20) / (kd * 4)));
+    const uint32_t kr = std::min<uint32_t>(k, kUpdateAccFloats / dim), ranges = (k + kr - 1) / kr;
+    const uint32_t threads = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
+    DevBufs bufs;
+    float *part, *total;
+    ST_TRY(bufs.alloc((size_t)(per_pass * kd), &part));
+    ST_TRY(bufs.alloc((size_t)kd, &total));
+    HIP_TRY(hipMemsetAsync(total, 0, kd * 4, stream));
+    hipLaunchKernelGGL(kmeans_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_assign, n, k, d_counts);
+    for (uint64_t c0 = 0; c0 < chunks; c0 += per_pass) {
+        const uint32_t nc = (uint32_t)std::min<uint64_t>(per_pass, chunks - c0);
+        hipLaunchKernelGGL(kmeans_partial_kernel, dim3(nc, ranges), dim3(threads), (size_t)kr * dim * 4 + kUpdateChunk * 4, stream,
+                           d_vectors, d_assign, n, dim, k, kr, c0, part);
+        hipLaunchKernelGGL(kmeans_fold_kernel, dim3((unsigned)((kd + 255) / 256)), dim3(256), 0, stream, part, nc, k, dim, total,
+                           d_counts, d_centroids, c0 + nc >= chunks ? 1u : 0u);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(stream)); // the workspace is freed on return
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_kmeanspp_init(const float *d_vectors, uint64_t n, uint32_t dim, uint32_t k, uint32_t metric,
+                                              uint64_t first, const float *uniforms, float *d_centroids, uint64_t *chosen,
+                                              int device_id, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_vectors || !d_centroids || (k > 1 && !uniforms)) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    if (dim == 0 || k == 0 || n == 0) return fail(CUDDLE_ERR_BAD_ARG, "dim, k and n must be >= 1");
+    if (k > n) return fail(CUDDLE_ERR_BAD_ARG, "k must be between 1 and the number of vectors"); // kmeans.rs:42
+    if (first >= n) return fail(CUDDLE_ERR_BAD_ARG, "first index out of range");
+    if (metric > CUDDLE_METRIC_DOT) return fail(CUDDLE_ERR_BAD_ARG, "unknown metric %u", metric);
+    ST_TRY(use_device(device_id));
+    DevBufs bufs;
+    float *mind, *w;
+    ST_TRY(bufs.alloc((size_t)n, &mind));
+    ST_TRY(bufs.alloc((size_t)n, &w));
+    float *hw = nullptr; // pinned: the weights come back every round
+    HIP_TRY(hipHostMalloc((void **)&hw, n * sizeof(float), hipHostMallocDefault));
+    struct Unpin { float *p; ~Unpin() { (void)hipHostFree(p); } } unpin{hw};
+    if (chosen) chosen[0] = first;
+    HIP_TRY(hipMemcpyAsync(d_centroids, d_vectors + first * dim, (size_t)dim * 4, hipMemcpyDeviceToDevice, stream));
+    for (uint32_t j = 1; j < k; ++j) {
+        hipLaunchKernelGGL(kmeanspp_round_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, stream, d_vectors, n, dim, metric,
+                           d_centroids + (size_t)(j - 1) * dim, mind, w, j == 1 ? 1u : 0u);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(hw, w, n * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        // kmeans.rs:67-77: both folds are sequential single-precision chains, which is what decides the draw
+        float total = 0.0f;
+        for (uint64_t v = 0; v < n; ++v) total += hw[v];
+        float target = uniforms[j - 1] * total;
+        uint64_t idx = 0;
+        for (uint64_t v = 0; v < n; ++v) {
+            target -= hw[v];
+            if (target <= 0.0f) {
+                idx = v;
+                break;
+            }
+        }
+        if (chosen) chosen[j] = idx;
+        HIP_TRY(hipMemcpyAsync(d_centroids + (size_t)j * dim, d_vectors + idx * dim, (size_t)dim * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_binary_encode_device(const float *d_vectors, uint64_t n, uint32_t dim, float threshold,
+                                                     uint64_t *d_codes, int device_id, void *stream_) {
+    if ((!d_vectors || !d_codes) && n) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    if (dim == 0) return fail(CUDDLE_ERR_BAD_ARG, "dim must be >= 1");
+    ST_TRY(use_device(device_id));
+    const uint32_t W = (dim + 63) / 64;
+    const uint64_t per = (1ull << 30); // (vector, word) pairs per launch: four per block
+    for (uint64_t v0 = 0; v0 < n;) {
+        const uint64_t nv = std::min<uint64_t>(n - v0, std::max<uint64_t>(1, per / W));
+        hipLaunchKernelGGL(binary_quantize_kernel, dim3((unsigned)((nv * W + 3) / 4)), dim3(256), 0, (hipStream_t)stream_,
+                           d_vectors + v0 * dim, nv, dim, W, threshold, d_codes + v0 * W);
+        v0 += nv;
+    }
+    HIP_TRY(hipGetLastError());
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_rabitq_encode_device(const float *d_rot_t, uint32_t dim, const float *d_vectors, uint64_t n,
+                                                     uint32_t *d_codes, float *d_norm, float *d_ip_oo, int device_id,
+                                                     void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_rot_t || ((!d_vectors || !d_codes || !d_norm || !d_ip_oo) && n)) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    if (dim == 0) return fail(CUDDLE_ERR_BAD_ARG, "dim must be >= 1");
+    constexpr int VB = 8;
+    if ((size_t)2 * VB * dim * 4 > (144u << 10)) return fail(CUDDLE_ERR_UNSUPPORTED, "dim %u too large for the encoder", dim);
+    ST_TRY(use_device(device_id));
+    if (n == 0) return CUDDLE_OK;
+    DevBufs bufs;
+    float *rot;
+    ST_TRY(bufs.alloc((size_t)dim * dim, &rot));
+    hipLaunchKernelGGL(transpose_square_kernel, dim3((dim + 255) / 256, dim), dim3(256), 0, stream, d_rot_t, rot, dim);
+    const size_t lds = (size_t)2 * VB * dim * 4;
+    if (lds > (64u << 10))
+        HIP_TRY(hipFuncSetAttribute((const void *)rabitq_encode_kernel<VB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(rabitq_encode_kernel<VB>, dim3((unsigned)((n + VB - 1) / VB)), dim3(256), lds, stream, d_vectors, rot, n, dim,
+                       d_codes, d_norm, d_ip_oo);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream)); // the transposed rotation is freed on return
     return CUDDLE_OK;
 }
 

@@ -149,7 +149,24 @@ struct PairOut {
     uint32_t *small = nullptr;
     uint32_t pstride = 0;
     uint32_t min_n = 0;
+    // seg != null: a grouped query's next frontier is not written out node by node; the query gets its
+    // segment table instead (seg + q * seg_stride(pstride)): start[0..pstride] = position of each chosen
+    // node's first child in the frontier (entries past the selection = the frontier's size), then
+    // cbase[0..pstride) = where the node's children start in the index's child array. frontier_node()
+    // maps a frontier position back to its node. Queries that are not grouped still get their frontier.
+    uint32_t *seg = nullptr;
 };
+__host__ __device__ __forceinline__ uint32_t seg_stride(uint32_t pstride) { return 2 * pstride + 2; }
+
+// Node at position `pos` of the frontier a segment table stands for (st: the query's table, LDS or global).
+__device__ __forceinline__ uint32_t frontier_node(const IndexDev &ix, const uint32_t *st, uint32_t pstride, uint32_t pos) {
+    uint32_t lo = 0, hi = pstride; // start[lo] <= pos < start[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (st[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return ix.children[st[pstride + 1 + lo] + (pos - st[lo])];
+}
 constexpr uint32_t kPairOffBits = 20; // next-frontier positions below 2^20, queries per chunk below 2^12
 constexpr int kGroupNQ = 8;           // queries per tile of route_dist_grouped_kernel
 constexpr int kGroupPairs = 64;       // pairs per block of route_dist_grouped_kernel (8 tiles)
@@ -226,15 +243,16 @@ __device__ __forceinline__ uint32_t reg_radix_select(const uint32_t (&keys)[KPT]
 // as the next frontier (:419-422; skipped when nf is null: the next level's frontier is then the
 // level's full node list, known without writing it per query). skeys[i] (low 32 bits) = position
 // in `fr` of the i-th chosen node. xs: 4 * cap1 u32 of LDS scratch, cap1 > nsel. All threads call.
-__device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t *fr, const uint64_t *skeys,
-                                             uint32_t nsel, uint32_t *xs, uint32_t cap1, uint32_t *nf,
-                                             uint32_t fstride, uint32_t *next_fcount_q, uint32_t *lv, uint32_t lstride,
-                                             uint32_t *lcount_q, const PairOut &po = PairOut(), uint32_t q = 0) {
+template <class NodeFn>
+__device__ __forceinline__ void route_expand_fn(const IndexDev &ix, NodeFn node_at, const uint64_t *skeys,
+                                                uint32_t nsel, uint32_t *xs, uint32_t cap1, uint32_t *nf,
+                                                uint32_t fstride, uint32_t *next_fcount_q, uint32_t *lv, uint32_t lstride,
+                                                uint32_t *lcount_q, const PairOut &po = PairOut(), uint32_t q = 0) {
     uint32_t *cnt_leaf = xs, *cnt_child = xs + cap1, *sel_node = xs + 2 * cap1, *sel_cb = xs + 3 * cap1;
     const uint32_t tid = threadIdx.x;
     const uint32_t lbase = *lcount_q; // read by every thread three barriers before thread 0 replaces it
     for (uint32_t i = tid; i < nsel; i += blockDim.x) {
-        const uint32_t node = fr[(uint32_t)skeys[i]];
+        const uint32_t node = node_at((uint32_t)skeys[i]);
         const uint32_t cb = ix.child_off[node], cc = ix.child_off[node + 1] - cb;
         cnt_leaf[i] = cc == 0 ? 1u : 0u;
         cnt_child[i] = cc;
@@ -250,9 +268,9 @@ __device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t 
         *lcount_q = min(lbase + cnt_leaf[nsel], lstride);
         if (nf) *next_fcount_q = min(cnt_child[nsel], fstride);
     }
+    const uint32_t nchild = cnt_child[nsel];
+    const bool grouped = po.info && nf && nchild > po.min_n && nchild <= fstride;
     if (po.info) {
-        const uint32_t nchild = cnt_child[nsel];
-        const bool grouped = nf && nchild > po.min_n && nchild <= fstride;
         for (uint32_t i = tid; i < po.pstride; i += blockDim.x) {
             uint32_t info = 0xFFFFFFFFu, par = 0, slot = 0;
             if (grouped && i < nsel && cnt_child[i + 1] > cnt_child[i]) {
@@ -266,6 +284,12 @@ __device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t 
         }
         if (tid == 0) po.small[q] = grouped ? 0u : 1u;
     }
+    const bool seg_only = grouped && po.seg;
+    if (seg_only) {
+        uint32_t *st = po.seg + (uint64_t)q * seg_stride(po.pstride);
+        for (uint32_t i = tid; i <= po.pstride; i += blockDim.x) st[i] = cnt_child[min(i, nsel)];
+        for (uint32_t i = tid; i < po.pstride; i += blockDim.x) st[po.pstride + 1 + i] = i < nsel ? sel_cb[i] : 0u;
+    }
     // leaves are appended by the thread of their selection slot; the children are copied one output
     // position per thread (the owning node found by bisection of the prefix sums in LDS), so that a
     // selection of many small families costs as little as one of a few large ones
@@ -274,7 +298,7 @@ __device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t 
             const uint32_t slot = lbase + cnt_leaf[i];
             if (slot < lstride) lv[slot] = sel_node[i];
         }
-    if (nf) {
+    if (nf && !seg_only) {
         const uint32_t total = min(cnt_child[nsel], fstride);
         for (uint32_t o = tid; o < total; o += blockDim.x) {
             uint32_t lo = 0, hi = nsel; // cnt_child[lo] <= o < cnt_child[hi]
@@ -285,6 +309,30 @@ __device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t 
             nf[o] = ix.children[sel_cb[lo] + (o - cnt_child[lo])];
         }
     }
+}
+
+__device__ __forceinline__ void route_expand(const IndexDev &ix, const uint32_t *fr, const uint64_t *skeys,
+                                             uint32_t nsel, uint32_t *xs, uint32_t cap1, uint32_t *nf,
+                                             uint32_t fstride, uint32_t *next_fcount_q, uint32_t *lv, uint32_t lstride,
+                                             uint32_t *lcount_q, const PairOut &po = PairOut(), uint32_t q = 0) {
+    route_expand_fn(ix, [&](uint32_t pos) { return fr[pos]; }, skeys, nsel, xs, cap1, nf, fstride, next_fcount_q, lv, lstride,
+                    lcount_q, po, q);
+}
+
+// The frontier of the queries with flag[q] != 0 that only have a segment table (small[q] == 0), written
+// out node by node for the kernels that walk whole frontiers. One block per query.
+__global__ void __launch_bounds__(256)
+route_materialise_kernel(IndexDev ix, const uint32_t *seg, uint32_t pstride, const uint32_t *flag, const uint32_t *small,
+                         uint32_t *frontier, uint32_t fstride, const uint32_t *fcount) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *st = reinterpret_cast<uint32_t *>(smem);
+    const uint32_t q = blockIdx.x;
+    if (!flag[q] || small[q]) return;
+    const uint32_t *sg = seg + (uint64_t)q * seg_stride(pstride);
+    for (uint32_t i = threadIdx.x; i < seg_stride(pstride); i += blockDim.x) st[i] = sg[i];
+    __syncthreads();
+    const uint32_t n = min(fcount[q], fstride);
+    for (uint32_t o = threadIdx.x; o < n; o += blockDim.x) frontier[(uint64_t)q * fstride + o] = frontier_node(ix, st, pstride, o);
 }
 
 // Level start: frontier = root_ids for every query (hierarchical.rs:346). write_roots = 0 when the
@@ -1212,7 +1260,7 @@ route_prefilter_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_
 // ncount != null: per-query frontiers of ncount[q] nodes (at most n); queries with skip[q] != 0 are
 // left alone; cand_cnt[q] = the query's number of candidates, min(kc, ncount[q]).
 template <int THREADS, int KPT>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KPT <= 20 ? 8 : 4)))
 route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_t kc, uint32_t *cand_pos,
                            uint32_t cstride, float *cand_max, const uint32_t *ncount = nullptr,
                            const uint32_t *skip = nullptr, uint32_t *cand_cnt = nullptr) {
@@ -1236,6 +1284,7 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
     }
     if (tid < 3) misc[1 + tid] = 0; // shortlist and winner counters (visible after the barriers inside the select)
     uint32_t *cp = cand_pos + (uint64_t)q * cstride;
+    CUDDLE_STAMP(8, 0);
     // Few candidates out of many keys: the kc-th smallest of the threads' own minima is an upper bound
     // T0 of the kc-th smallest key (kc minima, hence kc keys, are <= T0), and only a few more than kc
     // keys pass it. Selecting among the THREADS minima and then among that shortlist costs two cheap
@@ -1249,7 +1298,9 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
 #pragma unroll
         for (int t = 1; t < KPT; ++t) lmin[0] = min(lmin[0], keys[t]);
         uint32_t b0;
+        CUDDLE_STAMP(8, 1);
         const uint32_t T0 = reg_radix_select<THREADS, 1>(lmin, min(n, (uint32_t)THREADS), kc, hist, wred, b0);
+        CUDDLE_STAMP(8, 2);
         if (lmin[0] <= T0) {
 #pragma unroll
             for (int t = 0; t < KPT; ++t)
@@ -1260,6 +1311,7 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
         }
         __syncthreads(); // also: every wave is done with the first selection's counters
         const uint32_t m = misc[1];
+        CUDDLE_STAMP(8, 3);
         if (m <= SHORT) { // (more: many equal keys; the plain selection below handles any input)
             uint32_t k2[2];
 #pragma unroll
@@ -1273,6 +1325,7 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
         __syncthreads(); // the selection's counters may be reused below
     }
     if (!have) T = reg_radix_select<THREADS, KPT>(keys, n, kc, hist, wred, budget);
+    CUDDLE_STAMP(8, 4);
     // winners from the registers, i.e. roughly in level order: neighbouring candidates are neighbouring
     // rows of the centroid array, which the exact refinement reads next
     const uint32_t n_lt = kc - budget;
@@ -1290,6 +1343,7 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
         }
     }
     if (tid == 0) cand_max[q] = f32_from_key(T);
+    CUDDLE_STAMP(8, 5);
 }
 
 // Exact distance(query, centroid, metric) of the prefiltered nodes (levels on this path hold more
@@ -1300,9 +1354,11 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
 __global__ void __launch_bounds__(256)
 route_refine_kernel(IndexDev ix, const float *queries, const uint32_t *level_nodes, const uint32_t *cand_pos,
                     uint32_t cstride, uint32_t kc, float *cand_dist, const float *qnorm, uint32_t fstride = 0,
-                    const uint32_t *skip = nullptr, const uint32_t *cand_cnt = nullptr) {
+                    const uint32_t *skip = nullptr, const uint32_t *cand_cnt = nullptr, const uint32_t *seg = nullptr,
+                    uint32_t pstride = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);
+    uint32_t *st = reinterpret_cast<uint32_t *>(qs + ((ix.dim + 3) & ~3u)); // the query's segment table (seg != null)
     const uint32_t q = blockIdx.y, D = ix.dim;
     if (skip && skip[q]) return;
     if (cand_cnt) { // per-query frontiers: level_nodes is the array of frontiers, fstride nodes per query
@@ -1312,17 +1368,20 @@ route_refine_kernel(IndexDev ix, const float *queries, const uint32_t *level_nod
     }
     const float *qg = queries + (uint64_t)q * D;
     for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) qs[i] = qg[i];
+    if (seg)
+        for (uint32_t i = threadIdx.x; i < seg_stride(pstride); i += blockDim.x) st[i] = seg[(uint64_t)q * seg_stride(pstride) + i];
     __syncthreads();
     const uint32_t j = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
     const bool act = j < kc;
-    const uint32_t node = level_nodes[cand_pos[(uint64_t)q * cstride + (act ? j : 0)]];
+    const uint32_t cpos = cand_pos[(uint64_t)q * cstride + (act ? j : 0)];
+    const uint32_t node = seg ? frontier_node(ix, st, pstride, cpos) : level_nodes[cpos];
     float d = distance_group4_qn(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, (D & 3) == 0,
                                  ix.metric == kMetricCosine ? qnorm[q] : 0.f);
     if (act && sub == 0) cand_dist[(uint64_t)q * cstride + j] = d;
 }
 
-inline size_t route_finish_lds_bytes(uint32_t kpad, uint32_t probes) {
-    return (size_t)kpad * 8 + 4 * ((size_t)probes + 1) * 4 + 16;
+inline size_t route_finish_lds_bytes(uint32_t kpad, uint32_t probes) { // keys, expansion scratch, segment table
+    return (size_t)kpad * 8 + 4 * ((size_t)probes + 1) * 4 + (size_t)seg_stride(probes) * 4 + 16;
 }
 
 // Per query: sort the refined candidates by (exact distance, level position); the first `probes`
@@ -1338,11 +1397,13 @@ route_finish_kernel(IndexDev ix, const uint32_t *level_nodes, uint32_t n, const 
                     const float *cand_dist, uint32_t cstride, uint32_t kc, const float *cand_max, const float *qsq,
                     float max_csq, uint32_t probes, uint32_t *next_frontier, uint32_t fstride, uint32_t *next_fcount,
                     uint32_t *leaves, uint32_t lstride, uint32_t *lcount, uint32_t *flag, uint32_t *fallbacks, PairOut po,
-                    const uint32_t *ncount = nullptr, const uint32_t *skip = nullptr, const uint32_t *cand_cnt = nullptr) {
+                    const uint32_t *ncount = nullptr, const uint32_t *skip = nullptr, const uint32_t *cand_cnt = nullptr,
+                    const uint32_t *seg = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t kpad = next_pow2(kc);
     uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);
     uint32_t *xs = reinterpret_cast<uint32_t *>(skeys + kpad);
+    uint32_t *st = xs + 4 * (probes + 1); // this level's segment table of the query (seg != null)
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     if (skip && skip[q]) { // not on this path (small frontier): the exact kernels take the query
         if (tid == 0) flag[q] = 1;
@@ -1353,11 +1414,32 @@ route_finish_kernel(IndexDev ix, const uint32_t *level_nodes, uint32_t n, const 
         kc = cand_cnt[q];
         level_nodes += (uint64_t)q * fstride;
     }
-    for (uint32_t i = tid; i < kpad; i += blockDim.x)
-        skeys[i] = i < kc ? (((uint64_t)f32_key(cand_dist[(uint64_t)q * cstride + i]) << 32) | cand_pos[(uint64_t)q * cstride + i])
-                          : ~0ull;
-    __syncthreads();
-    block_sort_u64(skeys, kpad);
+    CUDDLE_STAMP(9, 0);
+    if (seg)
+        for (uint32_t i = tid; i < seg_stride(probes); i += blockDim.x) st[i] = seg[(uint64_t)q * seg_stride(probes) + i];
+    if (kpad <= 256) {
+        // few keys, all distinct (the position is part of the key): every thread finds its key's rank by
+        // counting the smaller ones, which takes one pass over LDS and two barriers
+        const uint64_t mine = tid < kc ? (((uint64_t)f32_key(cand_dist[(uint64_t)q * cstride + tid]) << 32) | cand_pos[(uint64_t)q * cstride + tid])
+                                       : ~0ull;
+        if (tid < kpad) skeys[tid] = mine;
+        __syncthreads();
+        CUDDLE_STAMP(9, 1);
+        uint32_t rank = 0;
+        if (tid < kc)
+            for (uint32_t j = 0; j < kc; ++j) rank += skeys[j] < mine ? 1u : 0u;
+        __syncthreads();
+        if (tid < kc) skeys[rank] = mine;
+        __syncthreads();
+    } else {
+        for (uint32_t i = tid; i < kpad; i += blockDim.x)
+            skeys[i] = i < kc ? (((uint64_t)f32_key(cand_dist[(uint64_t)q * cstride + i]) << 32) | cand_pos[(uint64_t)q * cstride + i])
+                              : ~0ull;
+        __syncthreads();
+        CUDDLE_STAMP(9, 1);
+        block_sort_u64(skeys, kpad);
+    }
+    CUDDLE_STAMP(9, 2);
     const float tau = f32_from_key((uint32_t)(skeys[probes - 1] >> 32));
     const float e = route_error_bound(ix.metric, ix.dim, qsq[q], max_csq);
     const bool ok = kc >= n || (cand_max[q] - e > tau);
@@ -1369,8 +1451,14 @@ route_finish_kernel(IndexDev ix, const uint32_t *level_nodes, uint32_t n, const 
         return;
     }
     if (tid == 0) flag[q] = 0;
-    route_expand(ix, level_nodes, skeys, probes, xs, probes + 1, next_frontier + (uint64_t)q * fstride, fstride,
-                 next_fcount + q, leaves + (uint64_t)q * lstride, lstride, lcount + q, po, q);
+    if (seg)
+        route_expand_fn(ix, [&](uint32_t pos) { return frontier_node(ix, st, probes, pos); }, skeys, probes, xs, probes + 1,
+                        next_frontier + (uint64_t)q * fstride, fstride, next_fcount + q, leaves + (uint64_t)q * lstride, lstride,
+                        lcount + q, po, q);
+    else
+        route_expand(ix, level_nodes, skeys, probes, xs, probes + 1, next_frontier + (uint64_t)q * fstride, fstride,
+                     next_fcount + q, leaves + (uint64_t)q * lstride, lstride, lcount + q, po, q);
+    CUDDLE_STAMP(9, 3);
 }
 
 } // namespace cuddle

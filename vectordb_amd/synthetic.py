@@ -87,38 +87,28 @@ class DeviceTreeIndex:
 
 
 def _pack_codes(x: torch.Tensor, threshold: float) -> torch.Tensor:
-    n, d = x.shape
-    words = (d + 63) // 64
-    b = torch.zeros((n, words * 64), dtype=torch.int64, device=x.device)
-    b[:, :d] = (x > threshold).to(torch.int64)
-    sh = torch.arange(32, device=x.device, dtype=torch.int64)
-    halves = (b.view(n, words, 2, 32) << sh).sum(-1)
-    return halves[..., 0] | (halves[..., 1] << 32)
+    """BinaryQuantizer::quantize of the rows: through the library for CUDA rows
+    (cuddle_binary_encode_device); CPU rows (the generator's gloo rehearsals) in torch."""
+    if x.is_cuda:
+        from .builder import binary_encode_device
+
+        return binary_encode_device(x, threshold)
+    from .builder import pack_binary_codes_torch
+
+    return torch.from_numpy(pack_binary_codes_torch(x, threshold).view(np.int64))
 
 
-def _rabitq_encode_device(vectors: torch.Tensor, rot_t: torch.Tensor, chunk: int = 1 << 18):
-    """RaBitQQuantizer::quantize (/root/reference/src/quantization/rabitq.rs:114-171) for a matrix
-    on the device, the formulation of builder.rabitq_encode: norm, sign code of the rotated unit
-    vector (bit i of u32 word i // 32), sum |rotated| as <o_bar, o>. Zero vectors: code 0, norm 0, 1.0."""
-    n, d = vectors.shape
-    words = (d + 31) // 32
-    codes = torch.empty((n, words), dtype=torch.int32, device=vectors.device)
-    norms = torch.empty(n, dtype=torch.float32, device=vectors.device)
-    ipoo = torch.empty(n, dtype=torch.float32, device=vectors.device)
-    sh = torch.arange(32, device=vectors.device, dtype=torch.int64)
-    for a in range(0, n, chunk):
-        v = vectors[a:a + chunk]
-        nr = v.norm(dim=1)
-        zero = nr < 1e-10
-        rot = (v / nr.clamp_min(1e-30)[:, None]) @ rot_t.t()
-        bits = torch.zeros((v.shape[0], words * 32), dtype=torch.int64, device=v.device)
-        bits[:, :d] = (rot >= 0).to(torch.int64)
-        bits[zero] = 0
-        w = (bits.view(-1, words, 32) << sh).sum(-1)            # 0 .. 2^32 - 1
-        codes[a:a + chunk] = torch.where(w >= (1 << 31), w - (1 << 32), w).to(torch.int32)
-        norms[a:a + chunk] = torch.where(zero, torch.zeros_like(nr), nr)
-        ipoo[a:a + chunk] = torch.where(zero, torch.ones_like(nr), rot.abs().sum(1))
-    return codes, norms, ipoo
+def _rabitq_encode_device(vectors: torch.Tensor, rot_t: torch.Tensor):
+    """RaBitQQuantizer::quantize_batch of the rows: through the library for CUDA rows
+    (cuddle_rabitq_encode_device); CPU rows in torch (builder.rabitq_encode)."""
+    if vectors.is_cuda:
+        from .builder import rabitq_encode_device
+
+        return rabitq_encode_device(vectors, rot_t)
+    from .builder import rabitq_encode
+
+    c, n, i = rabitq_encode(vectors, rot_t)
+    return torch.from_numpy(c.view(np.int32)), torch.from_numpy(n), torch.from_numpy(i)
 
 
 def build_tree_index_on_device(dim: int, fanout: int, levels: int, leaf_size: int, device, seed: int = 0,
@@ -189,10 +179,7 @@ def build_tree_index_on_device(dim: int, fanout: int, levels: int, leaf_size: in
     threshold = float((total / (n_leaves * leaf_size * dim)).item())
     codes, rq = None, {}
     if code_kind == _ffi.CODE_BINARY:
-        codes = torch.empty((n_vec, (dim + 63) // 64), dtype=torch.int64, device=device)
-        step = 1 << 20
-        for a in range(0, n_vec, step):
-            codes[a:a + step] = _pack_codes(vectors[a:a + step], threshold)
+        codes = _pack_codes(vectors, threshold)
     else:
         from .builder import make_rotation
         rot_t = torch.from_numpy(make_rotation(dim, seed + 17)).to(device)
