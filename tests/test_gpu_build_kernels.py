@@ -110,3 +110,17 @@ def test_rabitq_encode_device_matches_oracle(gpu, d, n):
     assert np.array_equal(_bits(norm.cpu().numpy()), _bits(want_norm))
     assert np.array_equal(_bits(ip.cpu().numpy()), _bits(want_ip))
     assert not codes[3].any() and float(norm[3]) == 0.0 and float(ip[3]) == 1.0
+
+
+def test_binary_encode_device_beyond_2_32_threads(gpu):
+    """One wave per (vector, word): 70M vectors are 4.5e9 threads, more than one launch can hold."""
+    dev = torch.device("cuda", gpu)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    n, d = 70_000_000, 8
+    x = torch.rand((n, d), generator=g, device=dev)
+    codes = B.binary_encode_device(x, 0.5)
+    sh = torch.arange(d, device=dev, dtype=torch.int64)
+    for a in (0, 33_554_432 - 1000, 67_108_864 - 1000, n - 2000):  # around the 2^25 / 2^26 marks and the tail
+        want = ((x[a:a + 2000] > 0.5).to(torch.int64) << sh).sum(1)
+        assert torch.equal(codes[a:a + 2000, 0], want), a

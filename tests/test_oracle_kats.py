@@ -242,3 +242,54 @@ def test_kmeans_assign_two_clusters_and_first_minimum():  # kmeans.rs:256-292; m
         a, d = orc.kmeans_assign(x, c, metric)
         full = np.stack([orc.distance_pairs(x, np.repeat(c[j:j + 1], 50, 0), metric) for j in range(9)], 1)
         assert np.array_equal(a, full.argmin(1)) and np.array_equal(d, full.min(1))
+
+
+def _oracle_kmeans_fit(x, k, metric, seed, iters=10):
+    """KMeans::fit (kmeans.rs:93-133) from the oracle's pieces, random draws from a seeded generator."""
+    rng = np.random.default_rng(seed)
+    cent, _ = orc.kmeanspp_init(x, k, metric, int(rng.integers(0, len(x))), rng.random(max(k - 1, 1)).astype(np.float32))
+    a, _ = orc.kmeans_assign(x, cent, metric)
+    prev = a.copy()
+    for _ in range(min(iters, 12)):
+        cent, counts = orc.kmeans_update(x, a, k, cent)
+        for e in np.nonzero(counts == 0)[0]:
+            cent[e] = x[int(rng.integers(0, len(x)))]
+        a, _ = orc.kmeans_assign(x, cent, metric)
+        if (a != prev).mean() < 0.02:
+            break
+        prev = a.copy()
+    return cent, a
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_kmeans_simple_two_clusters(seed):  # kmeans.rs:256-292
+    rng = np.random.default_rng(100 + seed)
+    x = np.concatenate([rng.random((10, 2)) * 0.5, 10.0 + rng.random((10, 2)) * 0.5]).astype(np.float32)
+    cent, a = _oracle_kmeans_fit(x, 2, _ffi.METRIC_L2, seed)
+    assert len(a) == 20 and len(set(a[:10])) == 1 and len(set(a[10:])) == 1 and a[0] != a[10]
+
+
+def test_kmeans_get_clusters_and_nearest():  # kmeans.rs:295-328
+    x = np.array([[1.0, 0.0], [1.1, 0.1], [10.0, 10.0], [10.1, 10.1]], dtype=np.float32)
+    cent, a = _oracle_kmeans_fit(x, 2, _ffi.METRIC_L2, 3)
+    assert sorted(np.bincount(a, minlength=2).tolist()) == [2, 2]
+    x3 = np.array([[1.0, 0.0], [0.0, 1.0], [10.0, 10.0]], dtype=np.float32)
+    cent, _ = _oracle_kmeans_fit(x3, 2, _ffi.METRIC_L2, 1)
+    near, _ = orc.kmeans_assign(np.array([[0.5, 0.5]], dtype=np.float32), cent, _ffi.METRIC_L2)
+    assert cent[near[0]][0] < 5.0 and cent[near[0]][1] < 5.0
+
+
+def test_kmeans_update_is_the_mean_and_keeps_empty_rows():  # kmeans.rs:204-215
+    x = np.array([[1, 2], [3, 4], [5, 6], [100, 100]], dtype=np.float32)
+    prev = np.full((3, 2), -7.0, dtype=np.float32)
+    cent, counts = orc.kmeans_update(x, np.array([0, 0, 0, 2]), 3, prev)
+    assert counts.tolist() == [3, 0, 1]
+    assert cent.tolist() == [[3.0, 4.0], [-7.0, -7.0], [100.0, 100.0]]
+
+
+def test_kmeanspp_walk_picks_by_cumulative_weight():  # kmeans.rs:66-79
+    x = np.array([[0.0], [1.0], [2.0], [10.0]], dtype=np.float32)
+    # first = 0: L2 distances 0, 1, 4, 100 -> weights 0, 1, 16, 10000 (total 10017)
+    for u, want in [(0.0, 0), (0.00005, 1), (0.001, 2), (0.5, 3), (0.9999, 3)]:
+        _, chosen = orc.kmeanspp_init(x, 2, _ffi.METRIC_L2, 0, np.array([u], dtype=np.float32))
+        assert chosen.tolist() == [0, want], (u, chosen)

@@ -1595,6 +1595,10 @@ extern "C" cuddle_status cuddle_kmeans_assign(const float *d_vectors, uint64_t n
     return CUDDLE_OK;
 }
 
+// A launch's threads (blocks x threads per block) must number fewer than 2^32: larger grids are cut short
+// without an error. Kernels whose grid grows with the number of stored vectors are launched in slices.
+constexpr uint64_t kMaxBlocksPerLaunch = 1ull << 23; // x 256 threads = 2^31
+
 extern "C" cuddle_status cuddle_kmeans_update(const float *d_vectors, uint64_t n, uint32_t dim, const uint32_t *d_assign,
                                               uint32_t k, float *d_centroids, uint32_t *d_counts, int device_id, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1610,12 +1614,16 @@ extern "C" cuddle_status cuddle_kmeans_update(const float *d_vectors, uint64_t n
     const uint64_t per_pass = std::max<uint64_t>(1, std::min<uint64_t>(chunks, (512ull << 20) / (kd * 4)));
     const uint32_t kr = std::min<uint32_t>(k, kUpdateAccFloats / dim), ranges = (k + kr - 1) / kr;
     const uint32_t threads = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
+    if (ranges > 65535) return fail(CUDDLE_ERR_UNSUPPORTED, "k * dim too large (%u cluster ranges)", ranges);
     DevBufs bufs;
     float *part, *total;
     ST_TRY(bufs.alloc((size_t)(per_pass * kd), &part));
     ST_TRY(bufs.alloc((size_t)kd, &total));
     HIP_TRY(hipMemsetAsync(total, 0, kd * 4, stream));
-    hipLaunchKernelGGL(kmeans_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_assign, n, k, d_counts);
+    for (uint64_t v0 = 0; v0 < n; v0 += kMaxBlocksPerLaunch * 256) {
+        const uint64_t nv = std::min<uint64_t>(n - v0, kMaxBlocksPerLaunch * 256);
+        hipLaunchKernelGGL(kmeans_count_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, d_assign + v0, nv, k, d_counts);
+    }
     for (uint64_t c0 = 0; c0 < chunks; c0 += per_pass) {
         const uint32_t nc = (uint32_t)std::min<uint64_t>(per_pass, chunks - c0);
         hipLaunchKernelGGL(kmeans_partial_kernel, dim3(nc, ranges), dim3(threads), (size_t)kr * dim * 4 + kUpdateChunk * 4, stream,
@@ -1648,8 +1656,11 @@ extern "C" cuddle_status cuddle_kmeanspp_init(const float *d_vectors, uint64_t n
     if (chosen) chosen[0] = first;
     HIP_TRY(hipMemcpyAsync(d_centroids, d_vectors + first * dim, (size_t)dim * 4, hipMemcpyDeviceToDevice, stream));
     for (uint32_t j = 1; j < k; ++j) {
-        hipLaunchKernelGGL(kmeanspp_round_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, stream, d_vectors, n, dim, metric,
-                           d_centroids + (size_t)(j - 1) * dim, mind, w, j == 1 ? 1u : 0u);
+        for (uint64_t v0 = 0; v0 < n; v0 += kMaxBlocksPerLaunch * 64) {
+            const uint64_t nv = std::min<uint64_t>(n - v0, kMaxBlocksPerLaunch * 64);
+            hipLaunchKernelGGL(kmeanspp_round_kernel, dim3((unsigned)((nv + 63) / 64)), dim3(256), 0, stream, d_vectors + v0 * dim, nv, dim,
+                               metric, d_centroids + (size_t)(j - 1) * dim, mind + v0, w + v0, j == 1 ? 1u : 0u);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(hw, w, n * sizeof(float), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1678,7 +1689,7 @@ extern "C" cuddle_status cuddle_binary_encode_device(const float *d_vectors, uin
     if (dim == 0) return fail(CUDDLE_ERR_BAD_ARG, "dim must be >= 1");
     ST_TRY(use_device(device_id));
     const uint32_t W = (dim + 63) / 64;
-    const uint64_t per = (1ull << 30); // (vector, word) pairs per launch: four per block
+    const uint64_t per = 4 * kMaxBlocksPerLaunch; // (vector, word) pairs per launch: four per block
     for (uint64_t v0 = 0; v0 < n;) {
         const uint64_t nv = std::min<uint64_t>(n - v0, std::max<uint64_t>(1, per / W));
         hipLaunchKernelGGL(binary_quantize_kernel, dim3((unsigned)((nv * W + 3) / 4)), dim3(256), 0, (hipStream_t)stream_,
@@ -1706,8 +1717,12 @@ extern "C" cuddle_status cuddle_rabitq_encode_device(const float *d_rot_t, uint3
     const size_t lds = (size_t)2 * VB * dim * 4;
     if (lds > (64u << 10))
         HIP_TRY(hipFuncSetAttribute((const void *)rabitq_encode_kernel<VB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(rabitq_encode_kernel<VB>, dim3((unsigned)((n + VB - 1) / VB)), dim3(256), lds, stream, d_vectors, rot, n, dim,
-                       d_codes, d_norm, d_ip_oo);
+    const uint32_t W32 = (dim + 31) / 32;
+    for (uint64_t v0 = 0; v0 < n; v0 += kMaxBlocksPerLaunch * VB) {
+        const uint64_t nv = std::min<uint64_t>(n - v0, kMaxBlocksPerLaunch * VB);
+        hipLaunchKernelGGL(rabitq_encode_kernel<VB>, dim3((unsigned)((nv + VB - 1) / VB)), dim3(256), lds, stream, d_vectors + v0 * dim, rot,
+                           nv, dim, d_codes + v0 * W32, d_norm + v0, d_ip_oo + v0);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream)); // the transposed rotation is freed on return
     return CUDDLE_OK;
