@@ -80,6 +80,9 @@ CONFIGS = {
     "tinytree": dict(n=8 ** 3 * 20, dim=32, n_queries=128, k=10, metric="l2", style="sift", probes=16,
                      rerank_sweep=[5, 10, 25, 50], code_kind="binary", tree=(8, 3, 20), gt_queries=128,
                      label="tiny tree by construction (8-way x 3 levels, 20-vector leaves per GPU)"),
+    "tinyrq": dict(n=8 ** 3 * 20, dim=48, n_queries=128, k=10, metric="cosine", style="gauss", probes=16,
+                   rerank_sweep=[5, 10, 25], code_kind="rabitq", tree=(8, 3, 20), gt_queries=128,
+                   label="tiny RaBitQ tree by construction (8-way x 3 levels, 20-vector leaves per GPU)"),
 }
 
 

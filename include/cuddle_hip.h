@@ -388,8 +388,8 @@ uint64_t cuddle_index_device_bytes(const cuddle_index *idx); /* index arrays + w
  * The shards' lists are then merged by (distance, order): cuddle_merge_topk_ordered, or the same
  * rule on the all-gathered device buffers (vectordb_amd/sharded.py).
  * All pointers are device pointers; work is enqueued on `stream`; 1..4096 queries per batch;
- * binary codes only. The handle keeps the batch's state between the calls: no other call on it
- * in between. */
+ * binary codes (RaBitQ codes: cuddle_shard_scan_rabitq below). The handle keeps the batch's state
+ * between the calls: no other call on it in between. */
 cuddle_status cuddle_shard_scan(cuddle_index *idx, const float *d_queries, uint32_t n_queries,
                                 uint32_t dim, uint32_t k, uint32_t probes_per_level,
                                 uint32_t rerank_factor, uint32_t flags, uint32_t *d_hist,
@@ -413,6 +413,30 @@ cuddle_status cuddle_shard_finish(cuddle_index *idx, const float *d_queries,
                                   float *d_out_dist, uint64_t *d_out_order, uint32_t *d_out_count,
                                   void *stream);
 
+/* The same for RaBitQ codes, whose phase-1 keys are f32 estimates (hierarchical_with_rabitq.rs:605-633): every
+ * shard makes the selection it would make alone (the rerank_k best of its own candidates; the selection of
+ * the whole index is a subset of the union of these) and names each member by a 64-bit key that orders
+ * candidates as the unsharded selection does: estimate, then leaf slot, then place in the leaf.
+ *   cuddle_shard_scan_rabitq   : query preparation, routing (d_leaves == NULL) or the given leaf lists, scan,
+ *                                the shard's own selection. d_keys [n_queries][R] receives its keys in
+ *                                ascending order, padded with UINT64_MAX; R = cuddle_rerank_k(k, rerank_factor,
+ *                                flags). -> the caller gathers the keys of all shards (all-gather).
+ *   cuddle_shard_finish_rabitq : d_all_keys [n_shards][n_queries][R]; the R-th smallest key over all shards
+ *                                is the threshold, the shard keeps its selection up to it, reranks, and returns
+ *                                its local top-k with d_out_order = the keys.
+ * The lists are merged as for binary codes (cuddle_merge_topk_ordered*). Leaf lists of fewer than 16384
+ * slots, leaves of at most 262144 vectors. */
+cuddle_status cuddle_rerank_k(uint32_t k, uint32_t rerank_factor, uint32_t flags, uint32_t *out);
+cuddle_status cuddle_shard_scan_rabitq(cuddle_index *idx, const float *d_queries, uint32_t n_queries,
+                                       uint32_t dim, uint32_t k, uint32_t probes_per_level,
+                                       uint32_t rerank_factor, uint32_t flags, const uint32_t *d_leaves,
+                                       uint32_t leaf_stride_in, const uint32_t *d_leaf_count,
+                                       uint64_t *d_keys, void *stream);
+cuddle_status cuddle_shard_finish_rabitq(cuddle_index *idx, const float *d_queries,
+                                         const uint64_t *d_all_keys, uint32_t n_shards,
+                                         uint64_t *d_out_ids, float *d_out_dist, uint64_t *d_out_order,
+                                         uint32_t *d_out_count, void *stream);
+
 /* ---- multi-GPU merge -------------------------------------------------------------------- */
 /* Merge `n_lists` per-shard result lists (each [n_queries][k], ascending, padded with
  * id = UINT64_MAX / +inf) into the global top-k per query, ties by (distance, list index,
@@ -431,7 +455,7 @@ cuddle_status cuddle_merge_topk_ordered(const uint64_t *lists_ids, const float *
                                         float *out_dist, uint32_t *out_count);
 
 /* The same merge on device buffers, enqueued on `stream` (what the ranks run on the all-gathered
- * lists): k <= 64 and n_lists * k <= 1024, else CUDDLE_ERR_UNSUPPORTED. list_stride_bytes = 0:
+ * lists): n_lists * k <= 1024, else CUDDLE_ERR_UNSUPPORTED. list_stride_bytes = 0:
  * the arrays are laid out [n_lists][n_queries][k] like the host merge's. Otherwise list l of each
  * of the three arrays ([n_queries][k]) starts list_stride_bytes (a multiple of 8) after list
  * l - 1, so that a rank's ids, distances and order keys can travel as one message. */
@@ -461,8 +485,9 @@ int cuddle_comm_world(const cuddle_comm *comm);
  * index's result bit for bit): routing split by queries + all-gather of the leaf lists,
  * cuddle_shard_scan_leaves + all-reduce of the Hamming histograms, cuddle_shard_ties +
  * all-reduce of the tie counts, cuddle_shard_finish + all-gather of the local top-k,
- * cuddle_merge_topk_ordered_device. Everything is enqueued on `stream`. Binary codes;
- * 1..4096 queries; k <= 64 and world * k <= 1024. */
+ * cuddle_merge_topk_ordered_device. With RaBitQ codes the two all-reduces are replaced by one all-gather
+ * of the shards' selection keys (cuddle_shard_scan_rabitq / cuddle_shard_finish_rabitq). Everything is
+ * enqueued on `stream`. 1..4096 queries; world * k <= 1024. */
 cuddle_status cuddle_sharded_search_batch(cuddle_index *shard, cuddle_comm *comm, const float *d_queries,
                                           uint32_t n_queries, uint32_t dim, uint32_t k,
                                           uint32_t probes_per_level, uint32_t rerank_factor,

@@ -71,12 +71,12 @@ def test_c_abi_communicator_world1(gpu):
     device = torch.device("cuda", gpu)
     uid = RcclShardedSearcher.make_unique_id()
     assert len(uid) == 128 and any(uid)
-    for metric, d in (("l2", 48), ("cosine", 320)):
-        x, fi = small_index(n=6000, d=d, n_clusters=40, branching=8, leaf=40, metric=metric)
+    for metric, d, kind in (("l2", 48, "binary"), ("cosine", 320, "binary"), ("l2", 64, "rabitq")):
+        x, fi = small_index(n=6000, d=d, n_clusters=40, branching=8, leaf=40, metric=metric, code_kind=kind)
         dev = DeviceIndex(fi, gpu)
         dq = torch.from_numpy(queries_like(x, 70, 3)).to(device)
-        s = RcclShardedSearcher(dev, 0, 1, uid if metric == "l2" else RcclShardedSearcher.make_unique_id())
-        for (k, probes, rf) in ((10, 4, 3), (1, 2, 1), (20, 8, 1000)):
+        s = RcclShardedSearcher(dev, 0, 1, uid if d == 48 else RcclShardedSearcher.make_unique_id())
+        for (k, probes, rf) in ((10, 4, 3), (1, 2, 1), (20, 8, 1000), (100, 6, 10)):
             ids0, d0, c0 = [t.clone() for t in dev.search_batch_device(dq, k, probes, rf)]
             ids1, d1, c1 = s.search_batch(dq, k, probes, rf)
             torch.cuda.synchronize()
@@ -84,6 +84,6 @@ def test_c_abi_communicator_world1(gpu):
             assert np.array_equal(d0.cpu().numpy().view(np.uint32), d1.cpu().numpy().view(np.uint32))
         # limits of the merge kernel are refused, not mis-computed
         with pytest.raises(_ffi.CuddleError) as e:
-            s.search_batch(dq, 65, 4, 3)
+            s.search_batch(dq, 1025, 4, 3)
         assert e.value.status == _ffi.ERR_UNSUPPORTED
         s.close()

@@ -114,17 +114,70 @@ class OracleShardEngine:
         return torch.from_numpy(ids), torch.from_numpy(dd), torch.from_numpy(order), torch.from_numpy(cnt)
 
 
+    # ---- RaBitQ codes: the key protocol (cuddle_shard_scan_rabitq / cuddle_shard_finish_rabitq) ----
+    @property
+    def selects_by_keys(self):
+        from vectordb_amd import _ffi
+        return int(self.fi.code_kind) == _ffi.CODE_RABITQ
+
+    @staticmethod
+    def _f32_key(bits):
+        bits = bits.astype(np.uint64)
+        return np.where(bits & 0x80000000, bits ^ 0xFFFFFFFF, bits | 0x80000000)
+
+    def shard_scan_keys(self, queries, k, probes, rf, leaves=None, leaf_count=None):
+        q = queries.numpy()
+        self.k, self.rerank_k = k, min(k * rf, 10000)
+        self.tr = [self.oi.search(q[i], k, probes, rf, trace=True) for i in range(q.shape[0])]
+        if leaves is not None:
+            self.given = True
+            for i, t in enumerate(self.tr):
+                assert int(leaf_count[i]) == len(t["leaves"]), i
+        keys = np.full((q.shape[0], self.rerank_k), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+        self.local = []
+        for i, t in enumerate(self.tr):
+            slot, inleaf = self._slots(t)
+            kk = (self._f32_key(t["cand_key"]) << np.uint64(32)) | (slot.astype(np.uint64) << np.uint64(18)) | inleaf.astype(np.uint64)
+            o = np.argsort(kk, kind="stable")[:self.rerank_k]
+            keys[i, :len(o)] = kk[o]
+            self.local.append((kk[o], t["cand_pos"][o].astype(np.int64)))
+        return torch.from_numpy(keys.view(np.int64))
+
+    def shard_finish_keys(self, queries, all_keys):
+        q = queries.numpy()
+        ak = all_keys.numpy().view(np.uint64)  # [world, nq, R]
+        nq, k = q.shape[0], self.k
+        ids = np.full((nq, k), -1, dtype=np.int64)
+        dd = np.full((nq, k), np.inf, dtype=np.float32)
+        order = np.full((nq, k), -1, dtype=np.int64)
+        cnt = np.zeros(nq, dtype=np.int32)
+        for i in range(nq):
+            allk = np.sort(ak[:, i, :].reshape(-1))
+            valid = allk[allk != np.uint64(0xFFFFFFFFFFFFFFFF)]
+            thr = valid[self.rerank_k - 1] if len(valid) > self.rerank_k else np.uint64(0xFFFFFFFFFFFFFFFE)
+            kk, pos = self.local[i]
+            m = kk <= thr
+            kk, pos = kk[m], pos[m]
+            if len(pos) == 0:
+                continue
+            d = self.orc.distance_pairs(np.repeat(q[i][None], len(pos), 0), self.fi.vectors[pos], int(self.fi.metric))
+            idx = np.lexsort((kk, d))[:k]
+            n = len(idx)
+            ids[i, :n], dd[i, :n], order[i, :n], cnt[i] = self.fi.ids[pos[idx]].astype(np.int64), d[idx], kk[idx].view(np.int64), n
+        return torch.from_numpy(ids), torch.from_numpy(dd), torch.from_numpy(order), torch.from_numpy(cnt)
+
+
 CASES = {"tight": (10, 4, 3), "mid": (10, 6, 10), "one": (1, 2, 1), "covering": (10, 4, 1000)}
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, code_kind="binary"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from vectordb_amd.sharded import ExactShardedSearcher
 
-        x, fi = small_index(n=4000, d=16, n_clusters=20, branching=6, leaf=30)
+        x, fi = small_index(n=4000, d=16, n_clusters=20, branching=6, leaf=30, code_kind=code_kind)
         q = queries_like(x, 24, 9)
         engine = OracleShardEngine(fi.shard(rank, world))
         searcher = ExactShardedSearcher(engine)
@@ -147,13 +200,13 @@ def _worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def _run(world, tmp_path):
+def _run(world, tmp_path, code_kind="binary"):
     from oracle import oracle as orc
 
     out = str(tmp_path / f"exact{world}.npz")
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, code_kind), nprocs=world, join=True)
     z = np.load(out)
-    x, fi = small_index(n=4000, d=16, n_clusters=20, branching=6, leaf=30)
+    x, fi = small_index(n=4000, d=16, n_clusters=20, branching=6, leaf=30, code_kind=code_kind)
     full = orc.OracleIndex(fi)
     for name, (k, probes, rf) in CASES.items():
         rc, ids, dd, cnt = full.search_batch(z["q"], k, probes, rf)
@@ -169,3 +222,8 @@ def test_two_rank_exact_sharded_search(tmp_path):
 
 def test_three_rank_exact_sharded_search(tmp_path):
     _run(3, tmp_path)
+
+
+def test_two_rank_exact_sharded_search_rabitq(tmp_path):
+    """RaBitQ codes: one all-gather of selection keys instead of the two all-reduces."""
+    _run(2, tmp_path, "rabitq")

@@ -138,6 +138,9 @@ SIGNATURES = {
     "cuddle_shard_scan": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, C.POINTER(_u32), _vp]),
     "cuddle_shard_ties": (_int, [_vp, _vp, _vp, _vp]),
     "cuddle_shard_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cuddle_rerank_k": (_int, [_u32, _u32, _u32, _vp]),
+    "cuddle_shard_scan_rabitq": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp]),
+    "cuddle_shard_finish_rabitq": (_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "cuddle_merge_topk_ordered": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "cuddle_comm_unique_id": (_int, [_vp]),
     "cuddle_comm_init": (_int, [_int, _int, _vp, _int, C.POINTER(_vp)]),

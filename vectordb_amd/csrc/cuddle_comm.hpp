@@ -135,8 +135,8 @@ extern "C" cuddle_status cuddle_sharded_search_batch(cuddle_index *shard, cuddle
     if (!shard || !comm || !d_queries || !d_out_ids || !d_out_dist) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
     if (shard->device != comm->device) return fail(CUDDLE_ERR_BAD_ARG, "the shard lives on device %d, the communicator on %d", shard->device, comm->device);
     if (n_queries == 0 || n_queries > kMaxChunk) return fail(CUDDLE_ERR_UNSUPPORTED, "1..%u queries per sharded batch", kMaxChunk);
-    if (k == 0 || k > 64 || (uint64_t)comm->world * k > 1024)
-        return fail(CUDDLE_ERR_UNSUPPORTED, "the sharded search merges k <= 64 and world * k <= 1024 results per query");
+    if (k == 0 || (uint64_t)comm->world * k > 1024)
+        return fail(CUDDLE_ERR_UNSUPPORTED, "the sharded search merges world * k <= 1024 results per query");
     std::lock_guard<std::mutex> lk(comm->mu);
     ST_TRY(use_device(comm->device));
     RcclApi &api = rccl_api();
@@ -150,9 +150,14 @@ extern "C" cuddle_status cuddle_sharded_search_batch(cuddle_index *shard, cuddle
     const size_t res_words = 2 * (size_t)nq * k + ((size_t)nq * k + 1) / 2;     // ids, order keys, f32 distances (8-byte words)
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const bool rabitq = shard->dev.code_kind == CUDDLE_CODE_RABITQ;
+    uint32_t rerank_k = 0;
+    ST_TRY(cuddle_rerank_k(k, rerank_factor, flags, &rerank_k));
+    const size_t key_words = rabitq ? (size_t)nq * rerank_k : 0; // RaBitQ: one key per member of a rank's own selection
     const size_t o_lmine = carve(msg_leaves), o_lall = carve(msg_leaves * world), o_lv = carve((size_t)world * per * lstride * 4),
-                 o_lc = carve((size_t)world * per * 4), o_hist = carve((size_t)nq * (D + 1) * 4), o_ties = carve((size_t)nq * lstride * 4),
-                 o_rmine = carve(res_words * 8), o_rall = carve(res_words * 8 * world);
+                 o_lc = carve((size_t)world * per * 4), o_hist = carve(rabitq ? 0 : (size_t)nq * (D + 1) * 4),
+                 o_ties = carve(rabitq ? 0 : (size_t)nq * lstride * 4), o_rmine = carve(res_words * 8), o_rall = carve(res_words * 8 * world),
+                 o_kmine = carve(key_words * 8), o_kall = carve(key_words * 8 * world);
     ST_TRY(comm->buf.ensure(off));
     char *b = static_cast<char *>(comm->buf.p);
     uint32_t *l_mine = (uint32_t *)(b + o_lmine), *l_all = (uint32_t *)(b + o_lall), *lv = (uint32_t *)(b + o_lv), *lc = (uint32_t *)(b + o_lc);
@@ -172,6 +177,18 @@ extern "C" cuddle_status cuddle_sharded_search_batch(cuddle_index *shard, cuddle
         HIP_TRY(hipMemcpyAsync(lv + (size_t)r * per * lstride, m, (size_t)per * lstride * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(lc + (size_t)r * per, m + (size_t)per * lstride * 4, (size_t)per * 4, hipMemcpyDeviceToDevice, s));
     }
+    const size_t n = (size_t)nq * k;
+    if (rabitq) {
+        // 2'. scan + this rank's own selection -> its keys, gathered from every rank; 3'. the ranks agree on the
+        // rerank_k-th smallest key, each keeps its selection up to it; 4'. as below
+        uint64_t *k_mine = (uint64_t *)(b + o_kmine), *k_all = (uint64_t *)(b + o_kall);
+        ST_TRY(cuddle_shard_scan_rabitq(shard, d_queries, nq, dim, k, probes_per_level, rerank_factor, flags, lv, lstride, lc, k_mine, s));
+        RCCL_TRY(api.AllGather(k_mine, k_all, key_words, ncclUint64, comm->comm, s));
+        ST_TRY(cuddle_shard_finish_rabitq(shard, d_queries, k_all, world, r_mine, (float *)(r_mine + 2 * n), r_mine + n, nullptr, s));
+        RCCL_TRY(api.AllGather(r_mine, r_all, res_words, ncclUint64, comm->comm, s));
+        return cuddle_merge_topk_ordered_device(r_all, (const float *)(r_all + 2 * n), r_all + n, world, nq, k, res_words * 8, d_out_ids,
+                                                d_out_dist, d_out_count, s);
+    }
     // 2. scan of this rank's leaves for the whole batch -> histograms summed over the ranks
     uint32_t stride_used = 0;
     ST_TRY(cuddle_shard_scan_leaves(shard, d_queries, nq, dim, k, probes_per_level, rerank_factor, flags, lv, lstride, lc, hist,
@@ -182,7 +199,6 @@ extern "C" cuddle_status cuddle_sharded_search_batch(cuddle_index *shard, cuddle
     ST_TRY(cuddle_shard_ties(shard, hist, ties, s));
     RCCL_TRY(api.AllReduce(ties, ties, (size_t)nq * lstride, ncclUint32, ncclSum, comm->comm, s));
     // 4. rerank + local top-k, written as one message: ids | order keys | distances
-    const size_t n = (size_t)nq * k;
     ST_TRY(cuddle_shard_finish(shard, d_queries, ties, r_mine, (float *)(r_mine + 2 * n), r_mine + n, nullptr, s));
     RCCL_TRY(api.AllGather(r_mine, r_all, res_words, ncclUint64, comm->comm, s));
     return cuddle_merge_topk_ordered_device(r_all, (const float *)(r_all + 2 * n), r_all + n, world, nq, k, res_words * 8, d_out_ids,

@@ -1919,15 +1919,19 @@ extern "C" cuddle_status cuddle_route_batch_device(cuddle_index *idx, const floa
     return CUDDLE_OK;
 }
 
+// d_hist != null: binary codes, histogram mode. d_keys != null: RaBitQ codes, the rank's own selection and its keys.
 static cuddle_status shard_scan_impl(cuddle_index *idx, const float *d_queries, uint32_t n_queries, uint32_t dim, uint32_t k,
                                      uint32_t probes_per_level, uint32_t rerank_factor, uint32_t flags, const uint32_t *d_leaves,
                                      uint32_t leaf_stride_in, const uint32_t *d_leaf_count, uint32_t *d_hist,
-                                     uint32_t *leaf_stride, void *stream) {
-    if (!idx || !d_queries || !d_hist) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+                                     uint32_t *leaf_stride, void *stream, uint64_t *d_keys = nullptr) {
+    if (!idx || !d_queries || (!d_hist && !d_keys)) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
     std::lock_guard<std::mutex> lk(idx->mu);
     ST_TRY(use_device(idx->device));
     idx->shard_state = 0;
-    if (idx->dev.code_kind != CUDDLE_CODE_BINARY) return fail(CUDDLE_ERR_UNSUPPORTED, "sharded exact selection needs binary codes");
+    if (d_hist && idx->dev.code_kind != CUDDLE_CODE_BINARY)
+        return fail(CUDDLE_ERR_UNSUPPORTED, "cuddle_shard_scan is for binary codes (RaBitQ codes: cuddle_shard_scan_rabitq)");
+    if (d_keys && idx->dev.code_kind != CUDDLE_CODE_RABITQ)
+        return fail(CUDDLE_ERR_UNSUPPORTED, "cuddle_shard_scan_rabitq is for RaBitQ codes (binary codes: cuddle_shard_scan)");
     if (dim != idx->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, idx->dev.dim);
     if (probes_per_level == 0) return fail(CUDDLE_ERR_BAD_ARG, "probes_per_level must be >= 1");
     if (n_queries == 0 || n_queries > kMaxChunk) return fail(CUDDLE_ERR_UNSUPPORTED, "1..%u queries per sharded batch", kMaxChunk);
@@ -1954,11 +1958,63 @@ static cuddle_status shard_scan_impl(cuddle_index *idx, const float *d_queries, 
         ST_TRY(launch_route(idx, pl, d_queries, n_queries, flags, s));
     }
     mark(idx, s, CUDDLE_STAGE_SCAN);
-    ST_TRY(launch_scan_select(idx, pl, n_queries, s, d_hist));
+    if (d_keys) {
+        if (pl.lstride >= (1u << kRqSlotBits)) return fail(CUDDLE_ERR_UNSUPPORTED, "leaf lists of %u slots: the key holds %u bits", pl.lstride, kRqSlotBits);
+        ST_TRY(launch_scan_select(idx, pl, n_queries, s));
+        hipLaunchKernelGGL(rq_exchange_keys_kernel, dim3(n_queries), dim3(256), (size_t)2 * pl.lstride * 4, s, idx->dev, pl.leaves, pl.lstride,
+                           pl.lcount, pl.lstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.rerank_k, d_keys, pl.sel_ord);
+        HIP_TRY(hipGetLastError());
+    } else {
+        ST_TRY(launch_scan_select(idx, pl, n_queries, s, d_hist));
+    }
     mark(idx, s, -1);
     idx->shard_nq = n_queries;
-    idx->shard_state = 1;
+    idx->shard_state = d_keys ? 3 : 1;
     if (leaf_stride) *leaf_stride = pl.lstride;
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_rerank_k(uint32_t k, uint32_t rerank_factor, uint32_t flags, uint32_t *out) {
+    if (!out) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+    uint64_t r;
+    ST_TRY(rerank_k_of(k, rerank_factor, flags, r));
+    *out = (uint32_t)r;
+    return CUDDLE_OK;
+}
+
+extern "C" cuddle_status cuddle_shard_scan_rabitq(cuddle_index *idx, const float *d_queries, uint32_t n_queries, uint32_t dim,
+                                                  uint32_t k, uint32_t probes_per_level, uint32_t rerank_factor, uint32_t flags,
+                                                  const uint32_t *d_leaves, uint32_t leaf_stride_in, const uint32_t *d_leaf_count,
+                                                  uint64_t *d_keys, void *stream) {
+    if (!d_keys || ((d_leaves == nullptr) != (d_leaf_count == nullptr))) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+    return shard_scan_impl(idx, d_queries, n_queries, dim, k, probes_per_level, rerank_factor, flags, d_leaves, leaf_stride_in,
+                           d_leaf_count, nullptr, nullptr, stream, d_keys);
+}
+
+extern "C" cuddle_status cuddle_shard_finish_rabitq(cuddle_index *idx, const float *d_queries, const uint64_t *d_all_keys,
+                                                    uint32_t n_shards, uint64_t *d_out_ids, float *d_out_dist,
+                                                    uint64_t *d_out_order, uint32_t *d_out_count, void *stream) {
+    if (!idx || !d_queries || !d_all_keys || !d_out_ids || !d_out_dist || !d_out_order || n_shards == 0)
+        return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    if (idx->shard_state != 3) return fail(CUDDLE_ERR_BAD_ARG, "cuddle_shard_finish_rabitq must follow cuddle_shard_scan_rabitq");
+    const Plan &pl = idx->shard_plan;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t nq = idx->shard_nq;
+    if ((uint64_t)n_shards * pl.rerank_k > 0xFFFFFFFFull) return fail(CUDDLE_ERR_UNSUPPORTED, "too many keys per query");
+    ST_TRY(enter_stream(idx, s));
+    mark(idx, s, CUDDLE_STAGE_SCAN);
+    uint64_t *thr = reinterpret_cast<uint64_t *>(pl.thr); // [nq] u64
+    hipLaunchKernelGGL(rq_threshold_kernel, dim3(nq), dim3(256), 0, s, d_all_keys, n_shards, nq, pl.rerank_k, thr);
+    hipLaunchKernelGGL(rq_cut_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, pl.sel_ord, pl.sstride, pl.sel_count, pl.rerank_k, thr, nq);
+    HIP_TRY(hipGetLastError());
+    mark(idx, s, CUDDLE_STAGE_RERANK);
+    ST_TRY(launch_rerank(idx, pl, d_queries, nq, s));
+    mark(idx, s, CUDDLE_STAGE_TOPK);
+    ST_TRY(launch_topk(idx, pl, nq, d_out_ids, d_out_dist, d_out_count, s, d_out_order));
+    mark(idx, s, -1);
+    idx->shard_state = 0;
     return CUDDLE_OK;
 }
 
@@ -2044,7 +2100,7 @@ extern "C" cuddle_status cuddle_merge_topk_ordered_device(const uint64_t *d_list
                                                           float *d_out_dist, uint32_t *d_out_count, void *stream) {
     if (!d_lists_ids || !d_lists_dist || !d_lists_order || !d_out_ids || !d_out_dist) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
     if (k == 0 || n_lists == 0) return fail(CUDDLE_ERR_BAD_ARG, "k and n_lists must be >= 1");
-    if (k > 64 || (uint64_t)n_lists * k > 64 * 16) return fail(CUDDLE_ERR_UNSUPPORTED, "device merge handles k <= 64 and n_lists * k <= 1024");
+    if ((uint64_t)n_lists * k > 64 * 16) return fail(CUDDLE_ERR_UNSUPPORTED, "device merge handles n_lists * k <= 1024");
     if (list_stride_bytes % 8) return fail(CUDDLE_ERR_BAD_ARG, "list_stride_bytes must be a multiple of 8");
     if (n_queries == 0) return CUDDLE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);

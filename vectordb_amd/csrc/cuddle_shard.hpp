@@ -14,11 +14,21 @@
 //      position among ALL ties (leaf slot order, then in-leaf order) is below the budget.
 // The union of the ranks' selections is then exactly the single-index selection, and the merge of
 // the ranks' top-k by (distance, Hamming distance, leaf slot, in-leaf position) is its top-k.
+//
+// RaBitQ codes: the phase-1 keys are f32 estimates, too many distinct values for a histogram. Every
+// rank selects its own rerank_k best as the unsharded search would (the global selection is a subset
+// of the union of those), names each by a 64-bit key that orders candidates exactly as the unsharded
+// selection does — (estimate, leaf slot, place in the leaf) — and the ranks all-gather the keys:
+//   1. rq_exchange_keys_kernel: the rank's sorted selection -> keys;
+//   2. rq_threshold_kernel: the rerank_k-th smallest of all ranks' keys (every rank computes the same);
+//   3. rq_cut_kernel: the rank keeps the prefix of its selection at or below that key.
 #pragma once
 
-#include "cuddle_kernels.hpp"
+#include "cuddle_route.hpp"
 
 namespace cuddle {
+
+constexpr uint32_t kRqSlotBits = 14, kRqLeafPosBits = 18; // key = f32_key(estimate) << 32 | leaf slot << 18 | place in leaf
 
 // thr[2q] = T, thr[2q+1] = budget; tie_count[q][slot] = local candidates of the slot at distance T
 // (0 for slots past the query's leaf list). One block per query; dynamic LDS =
@@ -147,7 +157,7 @@ shard_select_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const
 // Merge of the shards' result lists (cuddle_shard_finish: ascending, padded with id = ~0) into the
 // global top-k per query, ascending by (distance, order): the finalize_results order of the unsharded
 // index (hierarchical.rs:678-691). List l of an array ([nq][k]) starts that array's stride (bytes) after
-// list l - 1; n_lists * k <= 64 * KPL, k <= 64.
+// list l - 1; n_lists * k <= 64 * KPL.
 // One wave per query, entries in registers, k rounds of "smallest (distance, order) of the wave".
 template <int KPL>
 __global__ void __launch_bounds__(256)
@@ -175,7 +185,7 @@ merge_ordered_kernel(const uint64_t *ids, const float *dist, const uint64_t *ord
             }
         }
     }
-    uint32_t mine = 0xFFFFFFFFu, n = 0; // lane r keeps the entry index of the r-th winner
+    uint32_t n = 0;
     for (uint32_t r = 0; r < k; ++r) {
         uint32_t bd = dk[0], bt = 0;
         uint64_t bo = od[0];
@@ -192,9 +202,10 @@ merge_ordered_kernel(const uint64_t *ids, const float *dist, const uint64_t *ord
         const bool win = bd == md && bo == mo;       // order keys are unique: one lane
         const uint64_t wb = __ballot(win);
         const uint32_t src = (uint32_t)__ffsll((unsigned long long)wb) - 1;
-        const uint32_t e_w = (uint32_t)__builtin_amdgcn_readlane((int)(bt * 64 + lane), src);
-        if (lane == r) mine = e_w;
-        if (win && lane == src) {
+        if (win && lane == src) { // the r-th result, written by the lane that holds it
+            const uint32_t e_w = bt * 64 + lane;
+            out_ids[(uint64_t)q * k + r] = *at(ids, ids_stride, e_w);
+            out_dist[(uint64_t)q * k + r] = *at(dist, dist_stride, e_w);
 #pragma unroll
             for (int t = 0; t < KPL; ++t)
                 if ((uint32_t)t == bt) {
@@ -204,16 +215,90 @@ merge_ordered_kernel(const uint64_t *ids, const float *dist, const uint64_t *ord
         }
         ++n;
     }
-    for (uint32_t i = lane; i < k; i += 64) {
-        if (i < n) {
-            out_ids[(uint64_t)q * k + i] = *at(ids, ids_stride, mine);
-            out_dist[(uint64_t)q * k + i] = *at(dist, dist_stride, mine);
-        } else {
-            out_ids[(uint64_t)q * k + i] = ~0ull;
-            out_dist[(uint64_t)q * k + i] = __builtin_inff();
-        }
+    for (uint32_t i = n + lane; i < k; i += 64) {
+        out_ids[(uint64_t)q * k + i] = ~0ull;
+        out_dist[(uint64_t)q * k + i] = __builtin_inff();
     }
     if (lane == 0 && out_count) out_count[q] = n;
+}
+
+// keys[q][i] (i < rerank_k; ~0 past the rank's selection) and sel_ord[q][i] = the exchange key of the i-th
+// entry of the rank's sorted phase-1 selection. The leaf slot of an entry is found from its position:
+// the query's leaves own disjoint position ranges (leaves of other ranks are empty here).
+// One block per query; dynamic LDS = 2 * lcap * 4 bytes.
+__global__ void __launch_bounds__(256)
+rq_exchange_keys_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const uint32_t *lcount, uint32_t lcap,
+                        const uint32_t *sel_pos, const uint32_t *sel_key, uint32_t sel_stride, const uint32_t *sel_count,
+                        uint32_t rerank_k, uint64_t *keys, uint64_t *sel_ord) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lb = reinterpret_cast<uint32_t *>(smem), *le = lb + lcap;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t nl = min(lcount[q], lcap), n = min(min(sel_count[q], sel_stride), rerank_k);
+    for (uint32_t sl = tid; sl < nl; sl += blockDim.x) {
+        const uint32_t node = leaves[(uint64_t)q * lstride + sl];
+        lb[sl] = (uint32_t)ix.vec_off[node];
+        le[sl] = (uint32_t)ix.vec_off[node + 1];
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < rerank_k; i += blockDim.x) {
+        uint64_t key = ~0ull;
+        if (i < n) {
+            const uint32_t pos = sel_pos[(uint64_t)q * sel_stride + i];
+            uint32_t sl = 0;
+            while (sl + 1 < nl && !(pos >= lb[sl] && pos < le[sl])) ++sl;
+            key = ((uint64_t)f32_key(__uint_as_float(sel_key[(uint64_t)q * sel_stride + i])) << 32) |
+                  ((uint64_t)sl << kRqLeafPosBits) | (pos - lb[sl]);
+            sel_ord[(uint64_t)q * sel_stride + i] = key;
+        }
+        keys[(uint64_t)q * rerank_k + i] = key;
+    }
+}
+
+// thr[q] = the rerank_k-th smallest of the query's keys over all ranks (all_keys: [world][nq][rerank_k]); with
+// fewer than rerank_k candidates in all, every one of them is selected (thr = ~0 - 1; ~0 is padding).
+// Keys are distinct, so the selection is exactly the keys <= thr[q]. Two radix selections: the high
+// word, then the low word among the keys that share the threshold's high word. One block per query.
+__global__ void __launch_bounds__(256)
+rq_threshold_kernel(const uint64_t *all_keys, uint32_t world, uint32_t nq, uint32_t rerank_k, uint64_t *thr) {
+    __shared__ uint32_t hist[256], misc[2], wred[8], s_valid;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, n = world * rerank_k;
+    auto key_at = [&](uint32_t i) { return all_keys[((uint64_t)(i / rerank_k) * nq + q) * rerank_k + i % rerank_k]; };
+    if (tid == 0) s_valid = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < n; i += blockDim.x) mine += key_at(i) != ~0ull ? 1u : 0u;
+    if (mine) atomicAdd(&s_valid, mine);
+    __syncthreads();
+    if (s_valid <= rerank_k) {
+        if (tid == 0) thr[q] = ~0ull - 1;
+        return;
+    }
+    uint32_t budget;
+    const uint32_t hi = block_radix_select_aligned(n, rerank_k, [&](uint32_t i) { return (uint32_t)(key_at(i) >> 32); }, hist, misc,
+                                                   wred, budget);
+    __syncthreads();
+    uint32_t b2;
+    const uint32_t lo = block_radix_select_aligned(
+        n, budget, [&](uint32_t i) { const uint64_t k = key_at(i); return (uint32_t)(k >> 32) == hi ? (uint32_t)k : 0xFFFFFFFFu; },
+        hist, misc, wred, b2);
+    if (tid == 0) thr[q] = ((uint64_t)hi << 32) | lo;
+}
+
+// The rank's share of the global selection: its own selection is sorted by the same keys, so the share is
+// a prefix. sel_count[q] = number of the rank's keys <= thr[q].
+__global__ void __launch_bounds__(256)
+rq_cut_kernel(const uint64_t *sel_ord, uint32_t sel_stride, uint32_t *sel_count, uint32_t rerank_k, const uint64_t *thr,
+              uint32_t nq) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t n = min(min(sel_count[q], sel_stride), rerank_k);
+    const uint64_t t = thr[q], *k = sel_ord + (uint64_t)q * sel_stride;
+    uint32_t lo = 0, hi = n; // keys [0, lo) <= t < keys [hi, n)
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (k[mid] <= t) lo = mid + 1; else hi = mid;
+    }
+    sel_count[q] = lo;
 }
 
 } // namespace cuddle

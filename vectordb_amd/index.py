@@ -51,6 +51,7 @@ class DeviceIndex:
         _ffi.check(self._lib.cuddle_index_create(C.byref(desc), int(device_id), C.byref(self._handle)))
         self.device_id = int(device_id)
         self.dim = int(desc.dim)
+        self.code_kind = int(desc.code_kind)
         self.levels = int(self._lib.cuddle_index_levels(self._handle))
         self.max_leaf_size = int(self._lib.cuddle_index_max_leaf_size(self._handle))
         self.max_children = int(self._lib.cuddle_index_max_children(self._handle))
@@ -253,6 +254,60 @@ class DeviceIndex:
                                                  C.c_void_p(global_ties.data_ptr()), C.c_void_p(ids.data_ptr()),
                                                  C.c_void_p(dist.data_ptr()), C.c_void_p(order.data_ptr()),
                                                  C.c_void_p(count.data_ptr()), C.c_void_p(stream)))
+        return ids, dist, order, count
+
+    # ---- the same for RaBitQ codes: the shards exchange the keys of their own selections ----
+    @property
+    def selects_by_keys(self) -> bool:
+        """RaBitQ codes: the exact sharded protocol exchanges selection keys instead of histograms."""
+        return self.code_kind == _ffi.CODE_RABITQ
+
+    def shard_scan_keys(self, d_queries, k: int, probes_per_level: int, rerank_factor: int, flags: int = 0,
+                        stream: Optional[int] = None, leaves=None, leaf_count=None):
+        """Step 1 for RaBitQ codes (cuddle_shard_scan_rabitq): this shard's selection keys, int64 view of u64
+        [nq, rerank_k], ascending, padded with -1 (UINT64_MAX); to be all-gathered."""
+        import torch
+
+        assert d_queries.is_cuda and d_queries.dtype == torch.float32 and d_queries.is_contiguous()
+        nq, dim = d_queries.shape
+        if stream is None:
+            stream = torch.cuda.current_stream(d_queries.device).cuda_stream
+        r = C.c_uint32(0)
+        _ffi.check(self._lib.cuddle_rerank_k(k, rerank_factor, flags, C.byref(r)))
+        keys = torch.empty((nq, int(r.value)), dtype=torch.int64, device=d_queries.device)
+        lp, ls, lc = None, 0, None
+        if leaves is not None:
+            assert leaves.is_cuda and leaves.dtype == torch.int32 and leaves.stride(1) == 1 and leaves.shape[0] == nq
+            assert leaf_count.is_cuda and leaf_count.dtype == torch.int32 and leaf_count.is_contiguous()
+            lp, ls, lc = C.c_void_p(leaves.data_ptr()), leaves.stride(0), C.c_void_p(leaf_count.data_ptr())
+        _ffi.check(self._lib.cuddle_shard_scan_rabitq(self._handle, C.c_void_p(d_queries.data_ptr()), nq, dim, k, probes_per_level,
+                                                      rerank_factor, flags, lp, ls, lc, C.c_void_p(keys.data_ptr()), C.c_void_p(stream)))
+        self._shard = (nq, k, 0)
+        return keys
+
+    def shard_finish_keys(self, d_queries, all_keys, stream: Optional[int] = None, packed=None):
+        """Step 2 for RaBitQ codes (cuddle_shard_finish_rabitq): all_keys int64 [n_shards, nq, rerank_k] = every
+        shard's keys. Returns what shard_finish returns."""
+        import torch
+
+        nq, k, _ = self._shard
+        dev = d_queries.device
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        assert all_keys.is_cuda and all_keys.dtype == torch.int64 and all_keys.is_contiguous() and all_keys.shape[1] == nq
+        if packed is None:
+            ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            order = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        else:
+            assert packed.is_cuda and packed.dtype == torch.int64 and packed.is_contiguous() and packed.numel() >= self.packed_len(nq, k)
+            n = nq * k
+            ids, order = packed[:n].view(nq, k), packed[n:2 * n].view(nq, k)
+            dist = packed[2 * n:].view(torch.float32)[:n].view(nq, k)
+        count = torch.empty((nq,), dtype=torch.int32, device=dev)
+        _ffi.check(self._lib.cuddle_shard_finish_rabitq(self._handle, C.c_void_p(d_queries.data_ptr()), C.c_void_p(all_keys.data_ptr()),
+                                                        all_keys.shape[0], C.c_void_p(ids.data_ptr()), C.c_void_p(dist.data_ptr()),
+                                                        C.c_void_p(order.data_ptr()), C.c_void_p(count.data_ptr()), C.c_void_p(stream)))
         return ids, dist, order, count
 
     def last_stats(self) -> dict:

@@ -108,7 +108,7 @@ def merge_gathered_ordered(all_ids: torch.Tensor, all_dist: torch.Tensor, all_or
     """all_*: [world, nq, k]. Ascending by (distance, order), the rule of cuddle_merge_topk_ordered.
     Returns (ids [nq,k], dist [nq,k], count [nq])."""
     world, nq, kk = all_dist.shape
-    if all_dist.is_cuda and kk == k and k <= 64 and world * k <= 1024:  # one kernel (cuddle_merge_topk_ordered_device)
+    if all_dist.is_cuda and kk == k and world * k <= 1024:  # one kernel (cuddle_merge_topk_ordered_device)
         from . import _ffi
         ids = torch.empty((nq, k), dtype=torch.int64, device=all_dist.device)
         dd = torch.empty((nq, k), dtype=torch.float32, device=all_dist.device)
@@ -123,8 +123,8 @@ def merge_gathered_ordered(all_ids: torch.Tensor, all_dist: torch.Tensor, all_or
     o = all_order.permute(1, 0, 2).reshape(nq, world * kk)
     pad = i == PAD_ID
     d = torch.where(pad, torch.full_like(d, float("inf")), d)
-    # order keys are u64 seen through int64; their top bit is clear (Hamming < 2^15), pads sort last
-    o = torch.where(pad, torch.full_like(o, torch.iinfo(torch.int64).max), o)
+    # order keys are u64 seen through int64: flipping the top bit makes the signed order the unsigned one; pads sort last
+    o = torch.where(pad, torch.full_like(o, torch.iinfo(torch.int64).max), o ^ torch.iinfo(torch.int64).min)
     _, p1 = torch.sort(o, dim=1, stable=True)          # secondary key first ...
     d1, i1 = torch.gather(d, 1, p1), torch.gather(i, 1, p1)
     sd, p2 = torch.sort(d1, dim=1, stable=True)        # ... then a stable sort by the primary key
@@ -139,7 +139,7 @@ def merge_gathered_packed(everyone: torch.Tensor, nq: int, k: int):
     ids, order keys, f32 distances back to back). Same result as merge_gathered_ordered."""
     world, words = everyone.shape
     n = nq * k
-    if everyone.is_cuda and k <= 64 and world * k <= 1024:  # the merge kernel reads the messages in place
+    if everyone.is_cuda and world * k <= 1024:  # the merge kernel reads the messages in place
         from . import _ffi
         ids = torch.empty((nq, k), dtype=torch.int64, device=everyone.device)
         dd = torch.empty((nq, k), dtype=torch.float32, device=everyone.device)
@@ -196,25 +196,37 @@ class ExactShardedSearcher:
         return everyone[:, :stride].contiguous(), everyone[:, stride].contiguous()
 
     def search_batch(self, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int):
+        leaves = count = None
         if self.shard_routing:
             leaves, count = self._route_sharded(queries, probes_per_level)
-            hist = self.engine.shard_scan(queries, k, probes_per_level, rerank_factor, leaves=leaves, leaf_count=count)
+        if getattr(self.engine, "selects_by_keys", False):
+            # RaBitQ codes: every rank's own selection, named by keys that order candidates as the unsharded
+            # selection does; one all-gather of the keys, then each rank keeps what lies under the global threshold
+            keys = self.engine.shard_scan_keys(queries, k, probes_per_level, rerank_factor, leaves=leaves, leaf_count=count)
+            all_keys = torch.empty((self.world,) + tuple(keys.shape), dtype=keys.dtype, device=keys.device)
+            if self.world > 1:
+                _all_gather(all_keys, keys, self.group)
+            else:
+                all_keys[0] = keys
+            finish = lambda **kw: self.engine.shard_finish_keys(queries, all_keys, **kw)  # noqa: E731
         else:
-            hist = self.engine.shard_scan(queries, k, probes_per_level, rerank_factor)
-        if self.world > 1:
-            _all_reduce_sum(hist, self.group)
-        ties = self.engine.shard_ties(hist)
-        if self.world > 1:
-            _all_reduce_sum(ties, self.group)
+            hist = self.engine.shard_scan(queries, k, probes_per_level, rerank_factor, leaves=leaves, leaf_count=count) \
+                if leaves is not None else self.engine.shard_scan(queries, k, probes_per_level, rerank_factor)
+            if self.world > 1:
+                _all_reduce_sum(hist, self.group)
+            ties = self.engine.shard_ties(hist)
+            if self.world > 1:
+                _all_reduce_sum(ties, self.group)
+            finish = lambda **kw: self.engine.shard_finish(queries, ties, **kw)  # noqa: E731
         if self.packed and self.world > 1:
             nq = queries.shape[0]
             words = self.engine.packed_len(nq, k)
             mine = torch.empty((words,), dtype=torch.int64, device=queries.device)
-            self.engine.shard_finish(queries, ties, packed=mine)
+            finish(packed=mine)
             everyone = torch.empty((self.world, words), dtype=torch.int64, device=queries.device)
             _all_gather(everyone, mine, self.group)
             return merge_gathered_packed(everyone, nq, k)
-        ids, dist_, order, count = self.engine.shard_finish(queries, ties)
+        ids, dist_, order, count = finish()
         if self.world == 1:
             return ids, dist_, count
         nq = ids.shape[0]
@@ -248,19 +260,25 @@ def exact_search_in_process(engines, queries: torch.Tensor, k: int, probes_per_l
                      for r, e in enumerate(engines)]
             leaves = torch.cat([p[0] for p in parts]).contiguous()
             count = torch.cat([p[1] for p in parts]).contiguous()
-        hists = [e.shard_scan(queries, k, probes_per_level, rerank_factor, leaves=leaves, leaf_count=count) for e in engines]
+        lkw = dict(leaves=leaves, leaf_count=count)
     else:
-        hists = [e.shard_scan(queries, k, probes_per_level, rerank_factor) for e in engines]
-    ghist = torch.stack(hists).sum(dim=0).to(torch.int32).contiguous()
-    ties = [e.shard_ties(ghist) for e in engines]
-    gties = torch.stack(ties).sum(dim=0).to(torch.int32).contiguous()
+        lkw = {}
+    if getattr(engines[0], "selects_by_keys", False):  # RaBitQ codes: the shards' selection keys, concatenated
+        all_keys = torch.stack([e.shard_scan_keys(queries, k, probes_per_level, rerank_factor, **lkw) for e in engines]).contiguous()
+        finish = lambda e, **kw: e.shard_finish_keys(queries, all_keys, **kw)  # noqa: E731
+    else:
+        hists = [e.shard_scan(queries, k, probes_per_level, rerank_factor, **lkw) for e in engines]
+        ghist = torch.stack(hists).sum(dim=0).to(torch.int32).contiguous()
+        ties = [e.shard_ties(ghist) for e in engines]
+        gties = torch.stack(ties).sum(dim=0).to(torch.int32).contiguous()
+        finish = lambda e, **kw: e.shard_finish(queries, gties, **kw)  # noqa: E731
     if packed:
         words = engines[0].packed_len(nq, k)
         everyone = torch.empty((world, words), dtype=torch.int64, device=queries.device)
         for r, e in enumerate(engines):
-            e.shard_finish(queries, gties, packed=everyone[r])
+            finish(e, packed=everyone[r])
         return merge_gathered_packed(everyone, nq, k)
-    outs = [e.shard_finish(queries, gties) for e in engines]
+    outs = [finish(e) for e in engines]
     all_ids = torch.stack([o[0] for o in outs])
     all_dist = torch.stack([o[1] for o in outs])
     all_order = torch.stack([o[2] for o in outs])
