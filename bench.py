@@ -334,10 +334,15 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
         def route_device(self, q, pp, out=None):
             return dev_index.route_device(q, pp, flags, out=out)
 
+        def shard_scan_keys(self, q, kk, pp, rr, leaves=None, leaf_count=None):
+            return dev_index.shard_scan_keys(q, kk, pp, rr, flags, leaves=leaves, leaf_count=leaf_count)
+
+        selects_by_keys = dev_index.selects_by_keys  # RaBitQ codes: selection keys are exchanged, not histograms
         leaf_stride = staticmethod(dev_index.leaf_stride)
         packed_len = staticmethod(dev_index.packed_len)
         shard_ties = staticmethod(dev_index.shard_ties)
         shard_finish = staticmethod(dev_index.shard_finish)
+        shard_finish_keys = staticmethod(dev_index.shard_finish_keys)
 
     exact = world > 1 and args.sharded == "exact"
     # CUDDLE_BENCH_SHARD_ROUTING=0: every rank routes the whole batch (A/B against routing a slice each + all-gather)
