@@ -86,3 +86,23 @@ def test_stats_single_leaf_and_empty(gpu):
                                                  _ffi.ptr(out[2]), _ffi.ptr(out[3]), 4, _ffi.ptr(out[4]), _ffi.ptr(out[5]), 1,
                                                  _ffi.ptr(out[6]), _ffi.ptr(out[7]), _ffi.ptr(out[8]))
     assert st == _ffi.ERR_BAD_ARG  # level_stride < levels + 1
+
+
+def test_recall_diagnostic_breakdown(gpu):
+    """benches/recall_diagnostic.rs:96-146 on the GPU path: probing every leaf covers every true neighbour, a
+    generous rerank budget then returns all of them, and a narrow probe loses neighbours in routing only."""
+    from vectordb_amd.diagnostics import diagnose, summarise
+    x, fi = small_index(n=6000, d=32, n_clusters=40, branching=8, leaf=40, metric="l2")
+    q = queries_like(x, 32, 4)
+    d2 = ((q[:, None, :] - x[None, :, :]) ** 2).sum(-1)
+    gt = np.argsort(d2, axis=1, kind="stable")[:, :10]
+    ci = ClusteredIndex(fi, gpu)
+    wide = summarise(diagnose(ci, q, gt, 10, 1000, 1000), 10)
+    assert wide["probe_coverage"] == 1.0 and wide["final_recall"] == 1.0 and wide["leaves_probed_fraction"] == 1.0
+    narrow = diagnose(ci, q, gt, 10, 1, 1000)
+    s = summarise(narrow, 10)
+    assert s["leaves_probed_fraction"] < 0.2 and s["final_recall"] == s["probe_coverage"] <= 1.0  # everything probed is reranked
+    for m in narrow:
+        assert m.true_nns_in_final_results <= m.true_nns_in_rerank_candidates <= m.true_nns_in_probed_leaves <= 10
+    tight = summarise(diagnose(ci, q, gt, 10, 4, 1), 10)
+    assert tight["final_recall"] <= tight["rerank_coverage_upper_bound"] <= tight["probe_coverage"]

@@ -8,4 +8,6 @@ from ._ffi import CuddleError, METRIC_L2, METRIC_COSINE, METRIC_DOT, CODE_BINARY
 from .flat_index import FlatIndex, pack_binary_codes  # noqa: F401
 from .index import ClusteredIndex, ClusteredIndexWithRaBitQ, DeviceIndex, SearchStats  # noqa: F401
 
-__all__ = ["ClusteredIndex", "ClusteredIndexWithRaBitQ", "DeviceIndex", "FlatIndex", "SearchStats", "CuddleError"]
+from .pyvectordb import PyVectorDB  # noqa: E402
+
+__all__ = ["ClusteredIndex", "ClusteredIndexWithRaBitQ", "DeviceIndex", "FlatIndex", "SearchStats", "CuddleError", "PyVectorDB"]

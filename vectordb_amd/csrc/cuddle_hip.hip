@@ -361,6 +361,9 @@ static cuddle_status validate_desc(const cuddle_index_desc *d, std::vector<uint3
     if (d->code_kind == CUDDLE_CODE_BINARY && d->n_vectors && !d->codes) return fail(CUDDLE_ERR_BAD_ARG, "null codes");
     if (d->code_kind == CUDDLE_CODE_RABITQ && (!d->rabitq_rot_t || (d->n_vectors && (!d->rabitq_codes || !d->rabitq_norm || !d->rabitq_ip_oo))))
         return fail(CUDDLE_ERR_BAD_ARG, "null RaBitQ array");
+    if (d->code_kind == CUDDLE_CODE_RABITQ && (size_t)kPrepQ * d->dim * sizeof(float) > 144 * 1024)
+        return fail(CUDDLE_ERR_UNSUPPORTED, "RaBitQ codes: dim %u > %u (the query rotation stages %d queries in LDS)", d->dim,
+                    (unsigned)(144 * 1024 / (kPrepQ * sizeof(float))), kPrepQ);
     const uint32_t n = d->n_nodes;
     if (d->child_offsets[0] != 0 || d->vec_offsets[0] != 0) return fail(CUDDLE_ERR_BAD_INDEX, "offsets must start at 0");
     for (uint32_t i = 0; i < n; ++i) {
@@ -598,6 +601,7 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)grouped_kernel_for(v.dim, v.metric), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)rabitq_query_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_select_rabitq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_all_rabitq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)selection_sort_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

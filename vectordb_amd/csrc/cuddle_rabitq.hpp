@@ -18,17 +18,17 @@ __global__ void transpose_square_kernel(const float *src, float *dst, uint32_t d
     if (i < d && j < d) dst[(uint64_t)j * d + i] = src[(uint64_t)i * d + j];
 }
 
-constexpr int kPrepQ = 4; // queries per block of rabitq_query_prep_kernel
+constexpr int kPrepQ = 8; // queries per block of rabitq_query_prep_kernel
 
 // Query half of estimate_distances_batch_fast (rabitq.rs:398-420): qnorm = sqrt(sum q_j^2)
 // (sequential), qn = q / qnorm, rq[i] = sum_j rot_t[i][j] * qn[j] (rotate_query, :191-201,
 // sequential over j). One block handles kPrepQ queries so each rotation element is loaded once
-// for several queries; thread i owns output row i. rq is left untouched for qnorm < 1e-10.
-// Dynamic LDS: kPrepQ * dim floats.
+// for several queries (their component j side by side in LDS: two 16-byte reads per j); thread i
+// owns output row i. rq is left untouched for qnorm < 1e-10. Dynamic LDS: kPrepQ * dim floats.
 __global__ void __launch_bounds__(256)
 rabitq_query_prep_kernel(const float *queries, const float *rot, uint32_t nq, uint32_t dim, float *rq, float *qnorm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *qn = reinterpret_cast<float *>(smem); // [kPrepQ][dim]
+    float *qn = reinterpret_cast<float *>(smem); // [dim][kPrepQ]
     __shared__ float s_norm[kPrepQ];
     const uint32_t q0 = blockIdx.x * kPrepQ;
     if (threadIdx.x < kPrepQ) {
@@ -46,7 +46,7 @@ rabitq_query_prep_kernel(const float *queries, const float *rot, uint32_t nq, ui
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < kPrepQ * dim; t += blockDim.x) {
         const uint32_t qq = t / dim, j = t % dim, q = q0 + qq;
-        qn[t] = (q < nq && s_norm[qq] >= 1e-10f) ? queries[(uint64_t)q * dim + j] / s_norm[qq] : 0.f;
+        qn[j * kPrepQ + qq] = (q < nq && s_norm[qq] >= 1e-10f) ? queries[(uint64_t)q * dim + j] / s_norm[qq] : 0.f;
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) {
@@ -56,7 +56,7 @@ rabitq_query_prep_kernel(const float *queries, const float *rot, uint32_t nq, ui
         for (uint32_t j = 0; j < dim; ++j) {
             const float r = rot[(uint64_t)j * dim + i];
 #pragma unroll
-            for (int qq = 0; qq < kPrepQ; ++qq) acc[qq] += r * qn[qq * dim + j];
+            for (int qq = 0; qq < kPrepQ; ++qq) acc[qq] += r * qn[j * kPrepQ + qq];
         }
 #pragma unroll
         for (int qq = 0; qq < kPrepQ; ++qq)
