@@ -212,3 +212,31 @@ def test_device_array_rabitq_index_matches_oracle(gpu):
     for i in range(q.shape[0]):
         r = oi.search(q[i].cpu().numpy(), 10, 3, 5)
         assert np.array_equal(ids[i], r["ids"]) and np.array_equal(dist[i].view(np.uint32), r["dist"].view(np.uint32)), i
+
+
+def test_leaf_size_limit(gpu):
+    """The scan's tile tables hold the tile number inside a leaf in 12 bits: a leaf of 4096 * 64 vectors is the
+    largest that is searched (here a one-leaf index of exactly that size, checked against brute force), one more
+    vector is refused at cuddle_index_create."""
+    from vectordb_amd import _ffi
+    from vectordb_amd.flat_index import FlatIndex, pack_binary_codes
+
+    d = 8
+    rng = np.random.default_rng(3)
+
+    def one_leaf(n):
+        x = rng.standard_normal((n, d)).astype(np.float32)
+        return x, FlatIndex(dim=d, metric=_ffi.METRIC_L2, code_kind=_ffi.CODE_BINARY, centroids=x.mean(0, keepdims=True).astype(np.float32),
+                            child_offsets=np.array([0, 0], np.uint32), children=np.zeros(0, np.uint32), roots=np.array([0], np.uint32),
+                            vec_offsets=np.array([0, n], np.uint64), ids=np.arange(n, dtype=np.uint64), vectors=x,
+                            codes=pack_binary_codes(x, 0.0), threshold=0.0)
+
+    x, fi = one_leaf(4096 * 64)
+    dev = DeviceIndex(fi, gpu)
+    q = x[[5, 70000, 262143]] + np.float32(0.001)
+    ids, dist, cnt = dev.search_batch(q, 3, 1, 100000)  # rerank budget (capped at 10000) >> k: the true neighbours survive phase 1
+    assert cnt.tolist() == [3, 3, 3] and ids[:, 0].tolist() == [5, 70000, 262143]
+    _, big = one_leaf(4096 * 64 + 1)
+    with pytest.raises(_ffi.CuddleError) as e:
+        DeviceIndex(big, gpu)
+    assert e.value.status == _ffi.ERR_UNSUPPORTED

@@ -815,7 +815,7 @@ static cuddle_status launch_quantize(cuddle_index *ix, const Plan &pl, const flo
                            v.dim, v.words, ix->threshold, pl.qcodes);
     } else {
         float *rq = reinterpret_cast<float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
-        hipLaunchKernelGGL(rabitq_query_prep_kernel, dim3((nq + kPrepQ - 1) / kPrepQ), dim3(256), kPrepQ * v.dim * sizeof(float),
+        hipLaunchKernelGGL(rabitq_query_prep_kernel, dim3((nq + kPrepQ - 1) / kPrepQ), dim3(std::min(1024u, (v.dim + 63) & ~63u)), kPrepQ * v.dim * sizeof(float),
                            s, dq, v.rot, nq, v.dim, rq, qn);
     }
     HIP_TRY(hipGetLastError());

@@ -24,8 +24,9 @@ constexpr int kPrepQ = 8; // queries per block of rabitq_query_prep_kernel
 // (sequential), qn = q / qnorm, rq[i] = sum_j rot_t[i][j] * qn[j] (rotate_query, :191-201,
 // sequential over j). One block handles kPrepQ queries so each rotation element is loaded once
 // for several queries (their component j side by side in LDS: two 16-byte reads per j); thread i
-// owns output row i. rq is left untouched for qnorm < 1e-10. Dynamic LDS: kPrepQ * dim floats.
-__global__ void __launch_bounds__(256)
+// owns output row i (block = dim rounded up to whole waves, at most 1024 threads: the rows are the
+// parallelism). rq is left untouched for qnorm < 1e-10. Dynamic LDS: kPrepQ * dim floats.
+__global__ void __launch_bounds__(1024)
 rabitq_query_prep_kernel(const float *queries, const float *rot, uint32_t nq, uint32_t dim, float *rq, float *qnorm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qn = reinterpret_cast<float *>(smem); // [dim][kPrepQ]
