@@ -1,0 +1,68 @@
+"""GPU: routing over wide levels — a level of 4900 nodes shared by all queries followed by per-query frontiers of
+7000 nodes (children of the 100 chosen nodes, kept as segment tables), and a level whose approximate distances
+tie by the hundred. The leaf lists must equal the all-exact kernels' and the oracle's."""
+import numpy as np
+import pytest
+import torch
+
+from vectordb_amd import _ffi
+from vectordb_amd.flat_index import FlatIndex, pack_binary_codes
+from vectordb_amd.index import DeviceIndex
+from vectordb_amd.synthetic import build_tree_index_on_device
+
+pytestmark = pytest.mark.gpu
+
+
+def _lists(dev, q, probes, flags=0):
+    lv, lc = dev.route_batch(q, probes, flags)
+    return [lv[i, :lc[i]].tolist() for i in range(q.shape[0])]
+
+
+@pytest.mark.parametrize("metric", [_ffi.METRIC_L2, _ffi.METRIC_COSINE])
+def test_wide_shared_and_per_query_levels(gpu, metric):
+    from oracle import oracle as orc
+
+    device = torch.device("cuda", gpu)
+    # 70-way x 3 levels: level 1 has 4900 nodes (one frontier for all queries), level 2's frontiers are the
+    # 100 x 70 = 7000 children of the chosen nodes
+    dti, queries = build_tree_index_on_device(24, 70, 3, 3, device, seed=11, n_queries=96, metric=metric, style="gauss")
+    dev = dti.create(gpu)
+    q = queries.cpu().numpy()
+    probes = 100
+    got = _lists(dev, q, probes)
+    assert got == _lists(dev, q, probes, _ffi.SEARCH_ROUTE_EXACT_ONLY)
+    ids, dist, cnt, st = dev.search_batch(q, 10, probes, 5, want_stats=True)
+    assert st["route_fallbacks"] <= 4, st
+    oi = orc.OracleIndex(dti.to_flat())
+    for i in range(0, q.shape[0], 12):
+        t = oi.search(q[i], 10, probes, 5, trace=True)
+        assert got[i] == [int(v) for v in t["leaves"]], i
+        assert np.array_equal(ids[i, :cnt[i]], t["ids"][:t["count"]]), i
+
+
+def test_ties_flood_the_prefilter(gpu):
+    """A shared level of 6000 nodes with eight distinct centroids: every approximate distance ties with hundreds of
+    others, the prefilter's shortlist overflows and the proof fails at tied boundaries; the plain selection and the
+    exact kernels must still give the all-exact path's lists."""
+    rng = np.random.default_rng(3)
+    d, roots, fan = 16, 60, 100
+    n_nodes = roots + roots * fan
+    distinct = rng.standard_normal((8, d)).astype(np.float32)
+    cent = np.zeros((n_nodes, d), dtype=np.float32)
+    cent[:roots] = rng.standard_normal((roots, d)).astype(np.float32)
+    cent[roots:] = distinct[rng.integers(0, 8, roots * fan)]
+    child_offsets = np.zeros(n_nodes + 1, dtype=np.uint32)
+    child_offsets[1:roots + 1] = np.arange(1, roots + 1) * fan
+    child_offsets[roots + 1:] = roots * fan
+    children = np.arange(roots, n_nodes, dtype=np.uint32)
+    vec_offsets = np.zeros(n_nodes + 1, dtype=np.uint64)
+    vec_offsets[roots + 1:] = np.arange(1, roots * fan + 1) * 2
+    n = roots * fan * 2
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    fi = FlatIndex(dim=d, metric=_ffi.METRIC_L2, code_kind=_ffi.CODE_BINARY, centroids=cent, child_offsets=child_offsets,
+                   children=children, roots=np.arange(roots, dtype=np.uint32), vec_offsets=vec_offsets,
+                   ids=np.arange(n, dtype=np.uint64), vectors=x, codes=pack_binary_codes(x, 0.0), threshold=0.0)
+    dev = DeviceIndex(fi, gpu)
+    q = rng.standard_normal((40, d)).astype(np.float32)
+    assert _lists(dev, q, 100) == _lists(dev, q, 100, _ffi.SEARCH_ROUTE_EXACT_ONLY)
+    assert _lists(dev, q, 300) == _lists(dev, q, 300, _ffi.SEARCH_ROUTE_EXACT_ONLY)
