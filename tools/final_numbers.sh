@@ -7,11 +7,11 @@ tag=$1
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/gpu_tests.log 2>&1 || { tail -20 gpurun_out/gpu_tests.log; exit 1; }
 tail -2 gpurun_out/gpu_tests.log
 for c in gist1m sift1m; do timeout -k 10 400 python bench.py --config $c > gpurun_out/final_${tag}_$c.json 2> gpurun_out/final_${tag}_$c.err; done
-for c in shard12m shard125m rabitq10m; do timeout -k 10 400 python bench.py --config $c --no-cpu-baseline > gpurun_out/final_${tag}_$c.json 2> gpurun_out/final_${tag}_$c.err; done
+for c in shard12m shard125m rabitq10m gist10m; do timeout -k 10 400 python bench.py --config $c --no-cpu-baseline > gpurun_out/final_${tag}_$c.json 2> gpurun_out/final_${tag}_$c.err; done
 python3 - "$tag" <<'PY'
 import json, sys
 tag = sys.argv[1]
-for c in ("gist1m", "sift1m", "shard12m", "shard125m", "rabitq10m"):
+for c in ("gist1m", "sift1m", "shard12m", "shard125m", "rabitq10m", "gist10m"):
     j = json.loads(open(f"gpurun_out/final_{tag}_{c}.json").read().strip().splitlines()[-1])
     r = j["roofline"]
     cb = j.get("cpu_baseline") or {}
