@@ -348,6 +348,21 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
     # CUDDLE_BENCH_SHARD_ROUTING=0: every rank routes the whole batch (A/B against routing a slice each + all-gather)
     searcher = (ExactShardedSearcher(_ShardEngine(), shard_routing=os.environ.get("CUDDLE_BENCH_SHARD_ROUTING", "1") != "0")
                 if exact else ShardedSearcher(local_search))
+    if exact and args.collectives == "cabi":
+        # the same protocol with RCCL called by the library (cuddle_comm_* / cuddle_sharded_search_batch); the id
+        # made on rank 0 travels over the process group that is already up
+        from vectordb_amd.sharded import RcclShardedSearcher
+        if backend != "nccl":
+            raise SystemExit("--collectives cabi needs one GPU per rank (RCCL cannot place two ranks on one device)")
+        box = [RcclShardedSearcher.make_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        rccl = RcclShardedSearcher(dev_index, rank, world, box[0])
+
+        class _CabiSearcher:
+            def search_batch(self, q, kk, pp, rr):
+                return rccl.search_batch(q, kk, pp, rr, flags, out_ids, out_dist, out_cnt)
+
+        searcher = _CabiSearcher()
     step_no = [0]
 
     def step(batch=None):
@@ -545,6 +560,8 @@ def main():
     ap.add_argument("--threshold", default="mean", choices=["mean", "reference"],
                     help="binary threshold: exact mean, or the reference's saturating f32 running sum")
     ap.add_argument("--probes", type=int, default=0)
+    ap.add_argument("--collectives", default="torch", choices=["torch", "cabi"],
+                    help="N > 1, exact: who calls the collectives - torch.distributed (default) or the library itself through cuddle_comm_*")
     ap.add_argument("--sharded", default="exact", choices=["exact", "simple"],
                     help="N > 1: 'exact' reproduces the single-index result bit for bit (two small all-reduces + one "
                          "all-gather per batch); 'simple' lets every rank rerank its own top candidates (one all-gather)")
