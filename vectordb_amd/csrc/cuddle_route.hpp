@@ -939,10 +939,40 @@ center_queries_kernel(const float *queries, const float *mu, uint32_t nq, uint32
     if (q >= nq) return;
     uint16_t *row = out + (uint64_t)q * kp * 2;
     float s = 0.f;
-    for (uint32_t i = lane; i < kp; i += 64) {
-        float v = i < dim ? queries[(uint64_t)q * dim + i] - mu[i] : 0.f;
-        bf16_split_store(row, i, v);
-        s = __builtin_fmaf(v, v, s);
+    if ((dim & 3) == 0 && (kp & 7) == 0) {
+        // eight values per lane and step: two 16-byte loads, one 16-byte store each for the hi and the lo unit
+        const float *src = queries + (uint64_t)q * dim;
+        for (uint32_t g = lane; g < kp / 8; g += 64) {
+            float v[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t i = 8 * g + 4 * h;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f), m = x;
+                if (i < dim) { // dim is a multiple of 4: the four values are there or not
+                    x = *reinterpret_cast<const float4 *>(src + i);
+                    m = *reinterpret_cast<const float4 *>(mu + i);
+                }
+                v[4 * h] = x.x - m.x; v[4 * h + 1] = x.y - m.y; v[4 * h + 2] = x.z - m.z; v[4 * h + 3] = x.w - m.w;
+            }
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t h0 = bf16_round(v[2 * c]), h1 = bf16_round(v[2 * c + 1]);
+                hi[c] = h0 | (h1 << 16);
+                lo[c] = bf16_round(v[2 * c] - __uint_as_float(h0 << 16)) | (bf16_round(v[2 * c + 1] - __uint_as_float(h1 << 16)) << 16);
+                s = __builtin_fmaf(v[2 * c], v[2 * c], s);
+                s = __builtin_fmaf(v[2 * c + 1], v[2 * c + 1], s);
+            }
+            uint4 *dst = reinterpret_cast<uint4 *>(row + g * 16);
+            dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            dst[1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+    } else {
+        for (uint32_t i = lane; i < kp; i += 64) {
+            float v = i < dim ? queries[(uint64_t)q * dim + i] - mu[i] : 0.f;
+            bf16_split_store(row, i, v);
+            s = __builtin_fmaf(v, v, s);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
