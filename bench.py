@@ -441,6 +441,19 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
         return None
     recall = recall_of(ids)
 
+    # the host-pointer entry point (queries and results cross PCIe inside the call): reported beside `value`, never as it
+    host_entry = None
+    if world == 1:
+        qh = batches[0].cpu().numpy()
+        dev_index.search_batch(qh, k, probes, chosen, flags)
+        t1 = time.perf_counter()
+        for _ in range(10):
+            dev_index.search_batch(qh, k, probes, chosen, flags)
+        dt = (time.perf_counter() - t1) / 10
+        host_entry = {"queries_per_s": nq / dt, "ms_per_batch": dt * 1e3,
+                      "note": "cuddle_search_batch on host buffers: pageable H2D of the queries, the search, D2H of ids/distances/counts, synchronous"}
+        dev_index.stage_times()
+
     # ---- roofline of the dominant kernel (the code scan + select) --------------------------------
     rabitq = cfg["code_kind"] == "rabitq"
     code_bytes = (4 * ((cfg["dim"] + 31) // 32) + 8) if rabitq else 8 * ((cfg["dim"] + 63) // 64)
@@ -528,6 +541,7 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
                    "parallelism": (f"leaf-sharded x{world}, {args.sharded} selection" if world > 1 else "single GPU")},
         f"recall_at_{k}": recall,
         "recall_sweep": sweep,
+        "host_pointer_entry": host_entry,
         "reference_threshold": ref_threshold,
         "p50_batch_ms": lat[len(lat) // 2],
         "p99_batch_ms": lat[min(len(lat) - 1, len(lat) * 99 // 100)],
