@@ -612,7 +612,8 @@ def main():
         big = run_config("gist10m", args, rank, world, local_rank, device, backend, max(5, min(args.steps, 20)), 3,
                          want_cpu=False, want_filter=False)
         r = dict(big["roofline"])
-        r.update(workload=big["config"]["workload"], value=big["value"], unit=big["unit"], ms_per_step=big["ms_per_step"],
+        # the roofline's own "unit" (GB/s) stays; the probe's throughput goes beside it under its own names
+        r.update(workload=big["config"]["workload"], queries_per_s=big["value"], ms_per_step=big["ms_per_step"],
                  recall_at_10=big["recall_at_10"], candidates_per_query=big["candidates_per_query"])
         out["roofline_hbm_resident"] = r
     if rank == 0:
