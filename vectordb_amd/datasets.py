@@ -120,14 +120,16 @@ def read_staging(path: str, dim: int) -> np.ndarray:
 
 def synthetic_mixture(n: int, dim: int, seed: int, device="cpu", n_top: int = 100, n_sub: int = 10,
                       sigma_sub: float = 0.30, sigma: float = 0.25, style: str = "gist", n_queries: int = 0,
-                      latent_dim: int = 0, ambient_noise: float = 0.02):
+                      latent_dim: int = 0, ambient_noise: float = 0.02, query_block: int = 0):
     """Two-level Gaussian mixture on `device` (torch): n_top centres U(-1,1), n_sub sub-centres
     around each (sigma_sub), points around sub-centres (sigma). With latent_dim > 0 the mixture
     lives in R^latent_dim and is embedded in R^dim by a fixed random linear map plus a little
     isotropic noise — descriptor data has a low intrinsic dimension, and without one every
     neighbour of a point is (nearly) equally far away. style "sift" maps the result to
     non-negative integer-valued f32 in the u8 range; "gist" to small non-negative reals. Returns
-    (base [n,dim], queries [n_queries,dim]) float32 tensors; queries are held-out draws."""
+    (base [n,dim], queries [n_queries,dim]) float32 tensors; queries are held-out draws. With
+    query_block > 0 the queries are drawn query_block at a time, so a longer query set starts with
+    exactly the queries of a shorter one (the generator's output depends on the size of each draw)."""
     import torch
 
     g = torch.Generator(device=device)
@@ -156,7 +158,12 @@ def synthetic_mixture(n: int, dim: int, seed: int, device="cpu", n_top: int = 10
         return out
 
     base = draw(n)
-    queries = draw(n_queries) if n_queries else torch.empty((0, dim), device=device)
+    if not n_queries:
+        queries = torch.empty((0, dim), device=device)
+    elif query_block > 0 and n_queries > query_block:
+        queries = torch.cat([draw(min(query_block, n_queries - s)) for s in range(0, n_queries, query_block)])
+    else:
+        queries = draw(n_queries)
     return base, queries
 
 
