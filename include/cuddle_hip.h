@@ -288,7 +288,7 @@ cuddle_status cuddle_kmeans_assign(const float *d_vectors, uint64_t n, const flo
  * open; this merges from the left), then divided by the count as f32 (:209-213). The row of a cluster
  * without vectors is left untouched: the reference re-seeds it with a randomly drawn vector (:217-223),
  * which is the caller's draw to make. Assignments >= k are ignored. Device pointers: d_vectors [n][dim],
- * d_assign [n], d_centroids [k][dim], d_counts [k]. dim <= 11264. Allocates its workspace per call and
+ * d_assign [n], d_centroids [k][dim], d_counts [k]. dim <= 32768. Allocates its workspace per call and
  * returns after the work on `stream` has finished. */
 cuddle_status cuddle_kmeans_update(const float *d_vectors, uint64_t n, uint32_t dim, const uint32_t *d_assign,
                                    uint32_t k, float *d_centroids, uint32_t *d_counts, int device_id,
@@ -487,7 +487,8 @@ int cuddle_comm_world(const cuddle_comm *comm);
  * all-reduce of the tie counts, cuddle_shard_finish + all-gather of the local top-k,
  * cuddle_merge_topk_ordered_device. With RaBitQ codes the two all-reduces are replaced by one all-gather
  * of the shards' selection keys (cuddle_shard_scan_rabitq / cuddle_shard_finish_rabitq). Everything is
- * enqueued on `stream`. 1..4096 queries; world * k <= 1024. */
+ * enqueued on `stream`. Batches of more than 4096 queries run as equal rounds of at most 4096, one after the
+ * other; world * k <= 1024. */
 cuddle_status cuddle_sharded_search_batch(cuddle_index *shard, cuddle_comm *comm, const float *d_queries,
                                           uint32_t n_queries, uint32_t dim, uint32_t k,
                                           uint32_t probes_per_level, uint32_t rerank_factor,

@@ -240,3 +240,14 @@ def test_leaf_size_limit(gpu):
     with pytest.raises(_ffi.CuddleError) as e:
         DeviceIndex(big, gpu)
     assert e.value.status == _ffi.ERR_UNSUPPORTED
+
+
+def test_dimension_beyond_16384(gpu):
+    """A query vector of more than 64 KiB: the kernels that stage it in LDS (routing distances, refine, rerank)
+    need the raised dynamic-LDS limit. Same results as the oracle, bit for bit."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((300, 17000)).astype(np.float32)
+    fi = build_index(x, 4, 40, "l2", 4, seed=1)
+    dev = DeviceIndex(fi, gpu)
+    q = (x[:5] + 0.05 * rng.standard_normal((5, 17000))).astype(np.float32)
+    _compare_full(fi, dev, q, 5, 3, 4)

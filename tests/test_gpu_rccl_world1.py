@@ -82,6 +82,13 @@ def test_c_abi_communicator_world1(gpu):
             torch.cuda.synchronize()
             assert torch.equal(ids0, ids1) and torch.equal(c0, c1), (metric, k, probes, rf)
             assert np.array_equal(d0.cpu().numpy().view(np.uint32), d1.cpu().numpy().view(np.uint32))
+        if d == 48:  # more than 4096 queries: equal rounds of the protocol, one after the other
+            big = dq.repeat(65, 1)[:4500].contiguous()
+            ids0, d0, c0 = [t.clone() for t in dev.search_batch_device(big, 10, 4, 3)]
+            ids1, d1, c1 = s.search_batch(big, 10, 4, 3)
+            torch.cuda.synchronize()
+            assert torch.equal(ids0, ids1) and torch.equal(c0, c1)
+            assert np.array_equal(d0.cpu().numpy().view(np.uint32), d1.cpu().numpy().view(np.uint32))
         # limits of the merge kernel are refused, not mis-computed
         with pytest.raises(_ffi.CuddleError) as e:
             s.search_batch(dq, 1025, 4, 3)

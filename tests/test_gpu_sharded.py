@@ -161,3 +161,68 @@ def test_device_merge_matches_host_merge(gpu, world, k, nq):
     assert np.array_equal(o_ids.cpu().numpy().view(np.uint64), h_ids)
     # distances equal as floats (a signed zero may come from either of two tied lists only if their order keys tie, which they cannot)
     assert np.array_equal(_bits(o_dist.cpu().numpy()), _bits(h_dist))
+
+
+def _many_small_leaves(n_leaves, per_leaf, dim, seed, code_kind="binary"):
+    """A one-level index whose roots are its leaves: n_leaves leaves of per_leaf vectors each."""
+    from vectordb_amd import _ffi
+    from vectordb_amd.flat_index import FlatIndex, pack_binary_codes
+    rng = np.random.default_rng(seed)
+    cent = rng.uniform(-1, 1, (n_leaves, dim)).astype(np.float32)
+    x = (np.repeat(cent, per_leaf, axis=0) + 0.1 * rng.standard_normal((n_leaves * per_leaf, dim))).astype(np.float32)
+    thr = float(x.mean())
+    return x, FlatIndex(dim=dim, metric=0, code_kind=_ffi.CODE_BINARY, centroids=cent,
+                        child_offsets=np.zeros(n_leaves + 1, dtype=np.uint32), children=np.zeros(0, dtype=np.uint32),
+                        roots=np.arange(n_leaves, dtype=np.uint32),
+                        vec_offsets=(np.arange(n_leaves + 1, dtype=np.uint64) * per_leaf),
+                        ids=np.arange(n_leaves * per_leaf, dtype=np.uint64), vectors=x, threshold=thr,
+                        codes=pack_binary_codes(x, thr))
+
+
+def _two_levels_of_small_leaves(n_top, fan, per_leaf, dim, seed):
+    """n_top roots with `fan` leaf children each, per_leaf vectors per leaf (node ids: roots first, then the leaves)."""
+    from vectordb_amd import _ffi
+    from vectordb_amd.flat_index import FlatIndex, pack_binary_codes
+    rng = np.random.default_rng(seed)
+    top = rng.uniform(-1, 1, (n_top, dim)).astype(np.float32)
+    leaf_c = (np.repeat(top, fan, axis=0) + 0.3 * rng.standard_normal((n_top * fan, dim))).astype(np.float32)
+    n_leaves = n_top * fan
+    x = (np.repeat(leaf_c, per_leaf, axis=0) + 0.05 * rng.standard_normal((n_leaves * per_leaf, dim))).astype(np.float32)
+    thr = float(x.mean())
+    child_offsets = np.concatenate([np.arange(n_top + 1, dtype=np.uint32) * fan, np.full(n_leaves, n_leaves, dtype=np.uint32)])
+    vec_offsets = np.concatenate([np.zeros(n_top, dtype=np.uint64), np.arange(n_leaves + 1, dtype=np.uint64) * per_leaf])
+    return x, FlatIndex(dim=dim, metric=0, code_kind=_ffi.CODE_BINARY, centroids=np.concatenate([top, leaf_c]),
+                        child_offsets=child_offsets, children=(n_top + np.arange(n_leaves)).astype(np.uint32),
+                        roots=np.arange(n_top, dtype=np.uint32), vec_offsets=vec_offsets,
+                        ids=np.arange(n_leaves * per_leaf, dtype=np.uint64), vectors=x, threshold=thr,
+                        codes=pack_binary_codes(x, thr))
+
+
+def test_sharded_leaf_lists_beyond_64k_of_lds(gpu):
+    """Thousands of reached leaves per query: the leaf tables of the selection kernels (16 bytes per leaf slot plus
+    the query) pass the 64 KiB a kernel gets without asking for more, and the routing's last step has to fit its
+    candidates, expansion scratch and segment table into the CU's LDS or leave the level to the exact kernels.
+    Unsharded against the oracle, sharded against unsharded."""
+    from test_gpu_parity import _compare_full
+    x, fi = _many_small_leaves(5000, 2, 48, 3)
+    q = queries_like(x, 9, 5)
+    _compare_full(fi, DeviceIndex(fi, gpu), q, 10, 4096, 4)   # one level of 5000 > probes + margin: exact kernels
+    _check(fi, gpu, q, [(10, 4096, 4)], worlds=(2,))
+    x, fi = _two_levels_of_small_leaves(64, 100, 2, 32, 4)
+    q = queries_like(x, 7, 6)
+    _compare_full(fi, DeviceIndex(fi, gpu), q, 10, 3500, 2)   # shared level of 6400 through the filter, 3940 candidates
+    _compare_full(fi, DeviceIndex(fi, gpu), q, 10, 40, 2)     # per-query frontiers of 4000 through the grouped filter
+    _check(fi, gpu, q, [(10, 3500, 2)], worlds=(3,))
+
+
+def test_sharded_batch_larger_than_one_round(gpu):
+    """More than 4096 queries: ExactShardedSearcher cuts the batch into equal rounds."""
+    x, fi = small_index(n=3000, d=24, n_clusters=15, branching=6, leaf=25)
+    q = np.tile(queries_like(x, 100, 4), (45, 1))[:4300]
+    full = DeviceIndex(fi, gpu)
+    dq = torch.from_numpy(q).cuda(gpu)
+    ids0, d0, c0 = [t.clone() for t in full.search_batch_device(dq, 10, 4, 3)]
+    ids1, d1, c1 = ExactShardedSearcher(full).search_batch(dq, 10, 4, 3)  # a world of one, two rounds
+    torch.cuda.synchronize()
+    assert ids1.shape[0] == 4300 and torch.equal(ids0, ids1) and torch.equal(c0, c1)
+    assert np.array_equal(_bits(d0.cpu().numpy()), _bits(d1.cpu().numpy()))

@@ -128,17 +128,11 @@ extern "C" void cuddle_comm_destroy(cuddle_comm *c) {
 extern "C" int cuddle_comm_rank(const cuddle_comm *c) { return c ? c->rank : -1; }
 extern "C" int cuddle_comm_world(const cuddle_comm *c) { return c ? c->world : 0; }
 
-extern "C" cuddle_status cuddle_sharded_search_batch(cuddle_index *shard, cuddle_comm *comm, const float *d_queries,
-                                                     uint32_t n_queries, uint32_t dim, uint32_t k, uint32_t probes_per_level,
-                                                     uint32_t rerank_factor, uint32_t flags, uint64_t *d_out_ids,
-                                                     float *d_out_dist, uint32_t *d_out_count, void *stream) {
-    if (!shard || !comm || !d_queries || !d_out_ids || !d_out_dist) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
-    if (shard->device != comm->device) return fail(CUDDLE_ERR_BAD_ARG, "the shard lives on device %d, the communicator on %d", shard->device, comm->device);
-    if (n_queries == 0 || n_queries > kMaxChunk) return fail(CUDDLE_ERR_UNSUPPORTED, "1..%u queries per sharded batch", kMaxChunk);
-    if (k == 0 || (uint64_t)comm->world * k > 1024)
-        return fail(CUDDLE_ERR_UNSUPPORTED, "the sharded search merges world * k <= 1024 results per query");
-    std::lock_guard<std::mutex> lk(comm->mu);
-    ST_TRY(use_device(comm->device));
+// One round of the protocol for at most kMaxChunk queries (the caller holds comm->mu and has made the device current).
+static cuddle_status sharded_search_chunk(cuddle_index *shard, cuddle_comm *comm, const float *d_queries, uint32_t n_queries,
+                                          uint32_t dim, uint32_t k, uint32_t probes_per_level, uint32_t rerank_factor,
+                                          uint32_t flags, uint64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
+                                          void *stream) {
     RcclApi &api = rccl_api();
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t world = (uint32_t)comm->world, rank = (uint32_t)comm->rank, nq = n_queries, D = shard->dev.dim;
@@ -203,4 +197,28 @@ extern "C" cuddle_status cuddle_sharded_search_batch(cuddle_index *shard, cuddle
     RCCL_TRY(api.AllGather(r_mine, r_all, res_words, ncclUint64, comm->comm, s));
     return cuddle_merge_topk_ordered_device(r_all, (const float *)(r_all + 2 * n), r_all + n, world, nq, k, res_words * 8, d_out_ids,
                                             d_out_dist, d_out_count, s);
+}
+
+extern "C" cuddle_status cuddle_sharded_search_batch(cuddle_index *shard, cuddle_comm *comm, const float *d_queries,
+                                                     uint32_t n_queries, uint32_t dim, uint32_t k, uint32_t probes_per_level,
+                                                     uint32_t rerank_factor, uint32_t flags, uint64_t *d_out_ids,
+                                                     float *d_out_dist, uint32_t *d_out_count, void *stream) {
+    if (!shard || !comm || !d_queries || !d_out_ids || !d_out_dist) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+    if (shard->device != comm->device) return fail(CUDDLE_ERR_BAD_ARG, "the shard lives on device %d, the communicator on %d", shard->device, comm->device);
+    if (n_queries == 0) return fail(CUDDLE_ERR_BAD_ARG, "n_queries must be >= 1");
+    if (dim != shard->dev.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, shard->dev.dim);
+    if (k == 0 || (uint64_t)comm->world * k > 1024)
+        return fail(CUDDLE_ERR_UNSUPPORTED, "the sharded search merges world * k <= 1024 results per query");
+    std::lock_guard<std::mutex> lk(comm->mu);
+    ST_TRY(use_device(comm->device));
+    // larger batches run as equal rounds of at most kMaxChunk queries, one after the other on the stream (every rank
+    // cuts the batch the same way: the cut depends on n_queries alone)
+    const uint32_t rounds = (n_queries + kMaxChunk - 1) / kMaxChunk, per_round = (n_queries + rounds - 1) / rounds;
+    for (uint32_t q0 = 0; q0 < n_queries; q0 += per_round) {
+        const uint32_t qc = std::min(per_round, n_queries - q0);
+        ST_TRY(sharded_search_chunk(shard, comm, d_queries + (uint64_t)q0 * dim, qc, dim, k, probes_per_level, rerank_factor, flags,
+                                    d_out_ids + (uint64_t)q0 * k, d_out_dist + (uint64_t)q0 * k, d_out_count ? d_out_count + q0 : nullptr,
+                                    stream));
+    }
+    return CUDDLE_OK;
 }

@@ -605,6 +605,16 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     (void)hipFuncSetAttribute((const void *)scan_select_rabitq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_all_rabitq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)selection_sort_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // a query vector in LDS: more than 64 KiB from 16 385 dimensions on
+    (void)hipFuncSetAttribute((const void *)rerank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_dist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // the leaf tables of the sharded selection steps: 16 bytes per leaf slot
+    (void)hipFuncSetAttribute((const void *)shard_ties_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)shard_ties_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)shard_select_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)shard_select_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)rq_exchange_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError(); // attribute failures are not fatal: launches that need the space report them
     guard.p = nullptr;
     *out = ix;
@@ -890,6 +900,12 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
     bool grouped = false; // this level's distances come from the (query, parent) pairs of the level above
     bool have_seg = false; // ... and the grouped queries' frontiers exist as segment tables only (pl.seg[cur])
     static const bool no_filter = getenv("CUDDLE_GROUPED_EXACT") != nullptr; // tuning aid: exact distances for every pair
+    // the filter paths end in route_finish_kernel, whose LDS holds the sorted candidates, the expansion scratch and the
+    // segment table: with probes in the thousands and a level wider still that passes what a CU has, and the level
+    // goes through the exact kernels instead
+    auto finish_fits = [&](uint64_t width) {
+        return route_finish_lds_bytes(host_next_pow2((uint32_t)std::min<uint64_t>(width, pl.kc_cap)), pl.probes) <= 160 * 1024;
+    };
     for (uint32_t l = 0; l < ix->n_levels; ++l) {
         if (stats) // SearchStats::probes_per_level (hierarchical.rs:861): the frontier size of every query at this level
             HIP_TRY(hipMemcpyAsync(pl.level_fc + (size_t)l * pl.qc, pl.fcount[cur], (size_t)nq * 4, hipMemcpyDeviceToDevice, s));
@@ -915,7 +931,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         if (grouped) {
             // pairs recorded by the level above -> parent order -> one block per (parent, 8 queries)
             const uint32_t wprev = ix->level_width[l - 1], total = nq * pl.probes;
-            grouped_filter = !stats && g.n && bound <= 512 * 32 && !no_filter;
+            grouped_filter = !stats && g.n && bound <= 512 * 32 && !no_filter && finish_fits(bound);
             const uint32_t nb = (wprev + kPairScanChunk - 1) / kPairScanChunk; // pl.grp_fill: 2 * nb block sums / offsets
             hipLaunchKernelGGL(pair_block_sums_kernel, dim3(nb), dim3(256), 0, s, pl.grp_cnt, wprev, pl.grp_fill, nb);
             hipLaunchKernelGGL(pair_block_scan_kernel, dim3(1), dim3(1024), 0, s, pl.grp_fill, nb, wprev, pl.grp_poff, pl.grp_ioff);
@@ -968,7 +984,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 po.min_n = stats ? 0u : std::max<uint32_t>(pl.probes, 100);
                 // the next level will go through the contraction (the condition of grouped_filter there): its kernels
                 // need a frontier position's node for a few hundred positions per query, not the frontier itself
-                seg_next = !stats && ix->lvl[l + 1].n && bound_next <= 512 * 32 && !no_filter;
+                seg_next = !stats && ix->lvl[l + 1].n && bound_next <= 512 * 32 && !no_filter && finish_fits(bound_next);
                 if (seg_next) po.seg = pl.seg[cur ^ 1];
                 HIP_TRY(hipMemsetAsync(pl.grp_cnt, 0, ((size_t)ix->level_width[l] + 1) * 4, s));
             }
@@ -983,7 +999,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 hipLaunchKernelGGL(route_materialise_kernel, dim3(nq), dim3(256), seg_stride(pl.probes) * 4, s, v, pl.seg[cur], pl.probes,
                                    pl.rflag, pl.small_flag, pl.frontier[cur], pl.fstride, pl.fcount[cur]);
         }
-        const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound;
+        const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound && finish_fits(g.n);
         if (use_gemm) {
             const uint32_t n = g.n, kc = std::min(n, pl.kc_cap);
             launch_level_gemm(ix, pl, g, dq, nq, s);
@@ -1608,7 +1624,7 @@ extern "C" cuddle_status cuddle_kmeans_update(const float *d_vectors, uint64_t n
     hipStream_t stream = (hipStream_t)stream_;
     if (!d_centroids || !d_counts || ((!d_vectors || !d_assign) && n)) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
     if (dim == 0 || k == 0) return fail(CUDDLE_ERR_BAD_ARG, "dim and k must be >= 1");
-    if (dim > kUpdateAccFloats) return fail(CUDDLE_ERR_UNSUPPORTED, "dim %u > %u", dim, kUpdateAccFloats);
+    if (dim > 32768) return fail(CUDDLE_ERR_UNSUPPORTED, "dim %u > 32768", dim);
     if ((uint64_t)k * dim > (1ull << 31)) return fail(CUDDLE_ERR_UNSUPPORTED, "k * dim too large");
     ST_TRY(use_device(device_id));
     HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)k * 4, stream));
@@ -1616,7 +1632,11 @@ extern "C" cuddle_status cuddle_kmeans_update(const float *d_vectors, uint64_t n
     const uint64_t kd = (uint64_t)k * dim, chunks = (n + kUpdateChunk - 1) / kUpdateChunk;
     // chunks per pass: their partial sums ([chunks][k][dim] f32) stay within half a GiB (at least one chunk)
     const uint64_t per_pass = std::max<uint64_t>(1, std::min<uint64_t>(chunks, (512ull << 20) / (kd * 4)));
-    const uint32_t kr = std::min<uint32_t>(k, kUpdateAccFloats / dim), ranges = (k + kr - 1) / kr;
+    // clusters per block: what kUpdateAccFloats accumulators hold; one cluster (and more LDS) for longer vectors
+    const uint32_t kr = std::max<uint32_t>(1, std::min<uint32_t>(k, kUpdateAccFloats / dim)), ranges = (k + kr - 1) / kr;
+    const size_t partial_lds = (size_t)kr * dim * 4 + kUpdateChunk * 4;
+    if (partial_lds > (64u << 10))
+        HIP_TRY(hipFuncSetAttribute((const void *)kmeans_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)partial_lds));
     const uint32_t threads = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
     if (ranges > 65535) return fail(CUDDLE_ERR_UNSUPPORTED, "k * dim too large (%u cluster ranges)", ranges);
     DevBufs bufs;
@@ -1630,7 +1650,7 @@ extern "C" cuddle_status cuddle_kmeans_update(const float *d_vectors, uint64_t n
     }
     for (uint64_t c0 = 0; c0 < chunks; c0 += per_pass) {
         const uint32_t nc = (uint32_t)std::min<uint64_t>(per_pass, chunks - c0);
-        hipLaunchKernelGGL(kmeans_partial_kernel, dim3(nc, ranges), dim3(threads), (size_t)kr * dim * 4 + kUpdateChunk * 4, stream,
+        hipLaunchKernelGGL(kmeans_partial_kernel, dim3(nc, ranges), dim3(threads), partial_lds, stream,
                            d_vectors, d_assign, n, dim, k, kr, c0, part);
         hipLaunchKernelGGL(kmeans_fold_kernel, dim3((unsigned)((kd + 255) / 256)), dim3(256), 0, stream, part, nc, k, dim, total,
                            d_counts, d_centroids, c0 + nc >= chunks ? 1u : 0u);

@@ -195,7 +195,20 @@ class ExactShardedSearcher:
             return everyone[:, :stride], everyone[:, stride].contiguous()  # the lists stay where the gather put them
         return everyone[:, :stride].contiguous(), everyone[:, stride].contiguous()
 
+    MAX_ROUND = 4096  # queries per round of the protocol (the library's limit for one sharded batch)
+
     def search_batch(self, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int):
+        """Larger batches run as equal rounds of at most MAX_ROUND queries, one after the other (every rank cuts
+        the batch the same way: the cut depends on the batch size alone)."""
+        nq = queries.shape[0]
+        if nq <= self.MAX_ROUND:
+            return self._search_round(queries, k, probes_per_level, rerank_factor)
+        rounds = (nq + self.MAX_ROUND - 1) // self.MAX_ROUND
+        per = (nq + rounds - 1) // rounds
+        parts = [self._search_round(queries[q0:q0 + per], k, probes_per_level, rerank_factor) for q0 in range(0, nq, per)]
+        return tuple(torch.cat([p[i] for p in parts]) for i in range(3))
+
+    def _search_round(self, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int):
         leaves = count = None
         if self.shard_routing:
             leaves, count = self._route_sharded(queries, probes_per_level)
