@@ -27,7 +27,7 @@
  *   - limits (CUDDLE_ERR_UNSUPPORTED beyond them): dim <= 32768; fewer than 2^32 vectors per
  *     handle; at most 262144 vectors in one leaf; fewer than 2^25 candidates per query
  *     (leaf-list capacity x largest leaf); probes_per_level <= 4096 when a level is wider than
- *     4096 nodes; k * rerank_factor <= 16384 in the (uncapped) stats variant.
+ *     4096 nodes; in the (uncapped) stats variant min(k * rerank_factor, the candidates a query can reach) <= 16384.
  */
 #ifndef CUDDLE_HIP_H
 #define CUDDLE_HIP_H

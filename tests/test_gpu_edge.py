@@ -79,9 +79,7 @@ def test_error_codes(gpu):
         with pytest.raises(_ffi.CuddleError) as e:
             dev.search_batch(q, k, p, rf)
         assert e.value.status == _ffi.ERR_BAD_ARG        # k-1 underflow, hierarchical.rs:651
-    with pytest.raises(_ffi.CuddleError) as e:
-        dev.search_batch(q, 100, 2, 200, _ffi.SEARCH_STATS_VARIANT)  # uncapped 20000 > 16384
-    assert e.value.status == _ffi.ERR_UNSUPPORTED
+    _compare_full(fi, dev, q, 100, 2, 200, _ffi.SEARCH_STATS_VARIANT)  # uncapped 20000 > all 600 vectors: all of them
     ids, dist, cnt = dev.search_batch(q[:0], 5, 2, 3)    # empty batch
     assert ids.shape == (0, 5)
     # the handle still works after errors
@@ -146,6 +144,9 @@ def test_rerank_cap_and_spill_path(gpu):
     assert st["max_candidates"] > 24576, st
     assert st["vectors_reranked"] == 6 * 10000          # min(k*rf, 10000), hierarchical.rs:447
     _compare_full(fi, dev, q, 100, 800, 150)
+    with pytest.raises(_ffi.CuddleError) as e:           # uncapped variant: 20000 of > 24576 reachable candidates
+        dev.search_batch(q, 100, 800, 200, _ffi.SEARCH_STATS_VARIANT)
+    assert e.value.status == _ffi.ERR_UNSUPPORTED
 
 
 def test_batch_larger_than_one_chunk(gpu):
@@ -251,3 +252,15 @@ def test_dimension_beyond_16384(gpu):
     dev = DeviceIndex(fi, gpu)
     q = (x[:5] + 0.05 * rng.standard_normal((5, 17000))).astype(np.float32)
     _compare_full(fi, dev, q, 5, 3, 4)
+
+
+def test_selection_larger_than_the_index(gpu):
+    """search_with_stats has no cap on k * rerank_factor (hierarchical.rs:831-938): a selection far beyond the
+    candidates a query can reach means all of them, not an error."""
+    from vectordb_amd import _ffi
+    for kind in ("binary", "rabitq"):
+        x, fi = small_index(n=3000, d=24, n_clusters=15, branching=6, leaf=25, code_kind=kind)
+        dev = DeviceIndex(fi, gpu)
+        q = queries_like(x, 5, 4)
+        _compare_full(fi, dev, q, 3000, 6, 1000, _ffi.SEARCH_STATS_VARIANT)
+        _compare_full(fi, dev, q, 3000, 1000, 1000, _ffi.SEARCH_STATS_VARIANT)

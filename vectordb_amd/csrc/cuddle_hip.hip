@@ -702,8 +702,11 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
 
 // lstride_min: lower bound for the leaf-list capacity (stage entry points pass their own lists).
 // fixed_base != null: the work space is that device buffer of fixed_cap bytes (nothing is allocated).
+// whole_index: the selection is made over this index alone, so a selection size beyond the candidates a query can
+// reach means "all of them" and is cut to that bound (a shard of a sharded search keeps the size the ranks agreed on).
 static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32_t probes, uint64_t rerank_k64,
-                               uint32_t lstride_min, Plan &pl, void *fixed_base = nullptr, size_t fixed_cap = 0) {
+                               uint32_t lstride_min, Plan &pl, void *fixed_base = nullptr, size_t fixed_cap = 0,
+                               bool whole_index = true) {
     const IndexDev &v = ix->dev;
     if (probes > kSortCap) {
         // probes beyond every level's width behave as "keep / sort everything"; that is fine as
@@ -714,11 +717,9 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
             return fail(CUDDLE_ERR_UNSUPPORTED, "probes_per_level %u > %u with a level of %u nodes", probes, kSortCap, widest);
         probes = kSortCap;
     }
-    if (rerank_k64 > kMaxRerankK) return fail(CUDDLE_ERR_UNSUPPORTED, "k*rerank_factor %llu > %u", (unsigned long long)rerank_k64, kMaxRerankK);
     pl.qc = std::min(nq, kMaxChunk);
     pl.k = k;
     pl.probes = probes;
-    pl.rerank_k = (uint32_t)rerank_k64;
     // frontier bound: level 0 = roots; level l+1 <= min(width, min(probes, bound_l) * max_children)
     uint64_t fb = v.n_roots, fmax = v.n_roots, lsum = 0;
     for (uint32_t l = 0; l < ix->n_levels; ++l) {
@@ -735,6 +736,11 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     if (cbound >= kMaxCandidates || pl.lstride >= (1u << 20))
         return fail(CUDDLE_ERR_UNSUPPORTED, "a query may reach %llu candidates in %u leaves; at most %u candidates per query",
                     (unsigned long long)cbound, pl.lstride, kMaxCandidates - 1);
+    if (whole_index) rerank_k64 = std::min<uint64_t>(rerank_k64, std::max<uint64_t>(cbound, 1));
+    if (rerank_k64 > kMaxRerankK)
+        return fail(CUDDLE_ERR_UNSUPPORTED, "a selection of %llu candidates per query (k*rerank_factor, or all a query can reach) > %u",
+                    (unsigned long long)rerank_k64, kMaxRerankK);
+    pl.rerank_k = (uint32_t)rerank_k64;
     pl.cstride = (uint32_t)align_up(std::max<uint64_t>(cbound, 8), 128); // spill rows never share a cache line
     pl.sstride = (uint32_t)align_up(std::max<uint64_t>(std::min<uint64_t>(pl.rerank_k, cbound), 4), 4);
     pl.tcap = (uint32_t)align_up((size_t)pl.lstride + pl.cstride / 64 + 1, 4);
@@ -1968,7 +1974,7 @@ static cuddle_status shard_scan_impl(cuddle_index *idx, const float *d_queries, 
     HIP_TRY(hipMemsetAsync(idx->d_stats, 0, sizeof(DevStats), s));
     Plan &pl = idx->shard_plan;
     pl = Plan();
-    ST_TRY(make_plan(idx, n_queries, k, probes_per_level, rerank_k, 0, pl));
+    ST_TRY(make_plan(idx, n_queries, k, probes_per_level, rerank_k, 0, pl, nullptr, 0, /*whole_index=*/false));
     if (pl.qc < n_queries) return fail(CUDDLE_ERR_UNSUPPORTED, "%u queries do not fit the work-space budget in one chunk (%u do)", n_queries, pl.qc);
     if (idx->timed) idx->timed_searches++;
     mark(idx, s, CUDDLE_STAGE_QUANTIZE);
