@@ -22,11 +22,59 @@ from vectordb_amd.builder import build_index  # noqa: E402
 from vectordb_amd.index import DeviceIndex  # noqa: E402
 
 
+def random_tree_index(rng, d, metric, kind):
+    """An irregular forest made by hand (no k-means): 1..12 roots, depth up to 6, fan-out 1..9, leaves at any depth
+    holding 0, 1, 2, 3, 63, 64, 65, 200 or 1500 vectors; centroids near their parent's (they need not be means for
+    the search to be defined). Returns (vectors in stored order, FlatIndex)."""
+    import torch
+    from vectordb_amd.builder import make_rotation, metric_id, rabitq_encode
+    from vectordb_amd.flat_index import FlatIndex, pack_binary_codes
+    cents, kids, sizes = [], [], []
+
+    def add(parent_c, depth):
+        c = (parent_c + 0.5 * rng.standard_normal(d)).astype(np.float32)
+        me = len(cents)
+        cents.append(c); kids.append([]); sizes.append(0)
+        if depth >= int(rng.integers(1, 7)) or len(cents) > 3000:
+            sizes[me] = int(rng.choice([0, 1, 2, 3, 63, 64, 65, 200, 1500], p=[.1, .15, .15, .1, .1, .1, .1, .15, .05]))
+        else:
+            for _ in range(int(rng.integers(1, 10))):
+                kids[me].append(add(c, depth + 1))
+        return me
+
+    roots = [add(np.zeros(d, dtype=np.float32), 1) for _ in range(int(rng.integers(1, 13)))]
+    n_nodes = len(cents)
+    child_offsets = np.zeros(n_nodes + 1, dtype=np.uint32)
+    vec_offsets = np.zeros(n_nodes + 1, dtype=np.uint64)
+    children, rows = [], []
+    for i in range(n_nodes):
+        children.extend(kids[i])
+        child_offsets[i + 1] = len(children)
+        vec_offsets[i + 1] = vec_offsets[i] + np.uint64(sizes[i])
+        if sizes[i]:
+            rows.append((cents[i][None, :] + 0.2 * rng.standard_normal((sizes[i], d))).astype(np.float32))
+    x = np.concatenate(rows) if rows else np.zeros((0, d), dtype=np.float32)
+    if rng.random() < 0.3:
+        x = np.round(x * 2) / 2
+    fi = FlatIndex(dim=d, metric=metric_id(metric), code_kind=_ffi.CODE_BINARY if kind == "binary" else _ffi.CODE_RABITQ,
+                   centroids=np.stack(cents), child_offsets=child_offsets, children=np.asarray(children, dtype=np.uint32),
+                   roots=np.asarray(roots, dtype=np.uint32), vec_offsets=vec_offsets,
+                   ids=rng.permutation(x.shape[0]).astype(np.uint64), vectors=x)
+    if kind == "binary":
+        fi.threshold = float(x.mean()) if x.size else 0.0
+        fi.codes = pack_binary_codes(x, fi.threshold)
+    else:
+        fi.rabitq_rot_t = make_rotation(d, int(rng.integers(0, 1000)))
+        fi.rabitq_codes, fi.rabitq_norm, fi.rabitq_ip_oo = rabitq_encode(torch.from_numpy(x), torch.from_numpy(fi.rabitq_rot_t))
+    return x, fi.normalised()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=30)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--boundary", action="store_true")
+    ap.add_argument("--trees", action="store_true", help="hand-made irregular forests instead of k-means trees")
     ap.add_argument("--sharded", action="store_true",
                     help="also run the exact leaf-sharded protocol over 2..5 shards of the index (separate handles on the "
                          "one GPU) and compare it with the unsharded search bit for bit")
@@ -56,12 +104,19 @@ def main():
             k = int(rng.choice([1, 10, 50]))
             rf = int(rng.choice([1, 5, 30]))
             flags = int(rng.choice([0, 0, _ffi.SEARCH_STATS_VARIANT, _ffi.SEARCH_ROUTE_GROUPED]))
-        x = clustered(n, d, int(rng.integers(1 if args.boundary else 5, 200)), int(rng.integers(0, 1 << 30)),
-                      sigma=float(rng.choice([0.1, 0.3, 1.0])))
-        if rng.random() < 0.3:
-            x = np.round(x * 2) / 2  # coarse values: ties everywhere
         t0 = time.time()
-        fi = build_index(x, branching, leaf, metric, 5, seed=int(rng.integers(0, 1000)), code_kind=kind)
+        if args.trees:
+            d = min(d, 257)
+            x, fi = random_tree_index(rng, d, metric, kind)
+            n = x.shape[0]
+            if n == 0:
+                continue
+        else:
+            x = clustered(n, d, int(rng.integers(1 if args.boundary else 5, 200)), int(rng.integers(0, 1 << 30)),
+                          sigma=float(rng.choice([0.1, 0.3, 1.0])))
+            if rng.random() < 0.3:
+                x = np.round(x * 2) / 2  # coarse values: ties everywhere
+            fi = build_index(x, branching, leaf, metric, 5, seed=int(rng.integers(0, 1000)), code_kind=kind)
         dev = DeviceIndex(fi, 0)
         oi = orc.OracleIndex(fi)
         nq = int(rng.choice([1, 3, 64, 65])) if args.boundary else 64
