@@ -76,6 +76,10 @@ typedef enum cuddle_code_kind { CUDDLE_CODE_BINARY = 0, CUDDLE_CODE_RABITQ = 1 }
 /* Evaluate every level whose frontiers differ per query grouped by parent node, even where the
  * library would judge the frontiers too narrow for that to pay (bit-identical results; tests). */
 #define CUDDLE_SEARCH_ROUTE_GROUPED 0x8u
+/* A level that every query sees whole is filtered with single-pass half-precision matrix-core
+ * products where the index holds operands for it (levels below a level of at most 4096 nodes);
+ * this flag keeps the three-product split-bf16 filter there (bit-identical results; A/B, tests). */
+#define CUDDLE_SEARCH_ROUTE_SPLIT_FILTER 0x10u
 
 /* Flat description of one index (or one leaf shard of it). Mirrors ClusteredIndex's public
  * fields nodes/root_ids/quantizer/binary_vectors/full_vectors (hierarchical.rs:51-70) and

@@ -1,0 +1,96 @@
+"""GPU: the single-pass half-precision routing filter (a level every query sees whole). Its leaf lists must equal
+the split-bf16 filter's and the all-exact kernels' whatever the magnitude of the data, its measured error must stay
+inside the bound its proof uses, and where the proof cannot hold (a margin of one) the exact path must take over."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from vectordb_amd import _ffi
+from vectordb_amd.flat_index import FlatIndex, pack_binary_codes
+from vectordb_amd.index import DeviceIndex
+
+pytestmark = pytest.mark.gpu
+
+
+def _two_level(rng, d, roots, fan, metric, cent_fn):
+    """roots -> roots * fan leaves of two vectors each; the centroids of the wide level come from cent_fn."""
+    n_nodes = roots + roots * fan
+    cent = np.zeros((n_nodes, d), dtype=np.float32)
+    cent[:roots] = cent_fn(roots)
+    cent[roots:] = cent_fn(roots * fan)
+    child_offsets = np.zeros(n_nodes + 1, dtype=np.uint32)
+    child_offsets[1:roots + 1] = np.arange(1, roots + 1) * fan
+    child_offsets[roots + 1:] = roots * fan
+    children = np.arange(roots, n_nodes, dtype=np.uint32)
+    vec_offsets = np.zeros(n_nodes + 1, dtype=np.uint64)
+    vec_offsets[roots + 1:] = np.arange(1, roots * fan + 1) * 2
+    n = roots * fan * 2
+    x = np.repeat(cent[roots:], 2, axis=0).astype(np.float32)
+    return FlatIndex(dim=d, metric=metric, code_kind=_ffi.CODE_BINARY, centroids=cent, child_offsets=child_offsets,
+                     children=children, roots=np.arange(roots, dtype=np.uint32), vec_offsets=vec_offsets,
+                     ids=np.arange(n, dtype=np.uint64), vectors=x, codes=pack_binary_codes(x, 0.0), threshold=0.0)
+
+
+def _lists(dev, q, probes, flags=0):
+    lv, lc = dev.route_batch(q, probes, flags)
+    return [lv[i, :lc[i]].tolist() for i in range(q.shape[0])]
+
+
+CASES = {
+    "plain": lambda rng, d: (lambda m: rng.standard_normal((m, d)).astype(np.float32)),
+    "far_from_origin": lambda rng, d: (lambda m: (rng.standard_normal((m, d)) + 1000.0).astype(np.float32)),
+    "tiny": lambda rng, d: (lambda m: (rng.standard_normal((m, d)) * 1e-12).astype(np.float32)),
+    "huge": lambda rng, d: (lambda m: (rng.standard_normal((m, d)) * 1e12).astype(np.float32)),
+    # rows whose norms differ by ten orders of magnitude, components that differ by five inside a row
+    "mixed": lambda rng, d: (lambda m: (rng.standard_normal((m, d)) * 10.0 ** rng.integers(-5, 6, (m, 1))
+                                        * 10.0 ** rng.integers(-5, 1, (m, d))).astype(np.float32)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("metric", [_ffi.METRIC_L2, _ffi.METRIC_DOT, _ffi.METRIC_COSINE])
+@pytest.mark.parametrize("d", [24, 130])
+def test_half_filter_lists_equal_split_and_exact(gpu, metric, d, case):
+    rng = np.random.default_rng(zlib.crc32(f"{metric}/{d}/{case}".encode()))
+    gen = CASES[case](rng, d)
+    fi = _two_level(rng, d, 40, 75, metric, gen)  # level 1: 3000 nodes, whole for every query (40 roots <= probes)
+    if metric != _ffi.METRIC_COSINE:  # (the cosine distance to a zero vector is NaN, on which the reference panics)
+        fi.centroids[45] = 0.0
+        fi.centroids[1045] = 0.0
+    dev = DeviceIndex(fi, gpu)
+    q = gen(64)
+    for probes in (40, 100):
+        want = _lists(dev, q, probes, _ffi.SEARCH_ROUTE_EXACT_ONLY)
+        assert _lists(dev, q, probes) == want
+        assert _lists(dev, q, probes, _ffi.SEARCH_ROUTE_SPLIT_FILTER) == want
+    ratio, _ = dev.route_filter_error(q, 100, 1)
+    assert ratio < 1.0, ratio  # the proof's bound holds (it is the half-precision filter that is measured)
+
+
+def test_half_filter_error_is_the_half_filters(gpu):
+    """The diagnostic measures the filter a search uses: with rounding to 11 bits the error is far above what the
+    split operands leave, and still well inside its own bound."""
+    rng = np.random.default_rng(5)
+    gen = CASES["plain"](rng, 64)
+    dev = DeviceIndex(_two_level(rng, 64, 40, 75, _ffi.METRIC_L2, gen), gpu)
+    q = gen(32)
+    ratio, err = dev.route_filter_error(q, 100, 1)
+    assert 1e-4 < ratio < 0.5, (ratio, err)
+
+
+def test_margin_of_one_falls_back_to_the_exact_kernels(gpu):
+    rng = np.random.default_rng(9)
+    gen = CASES["plain"](rng, 24)
+    dev = DeviceIndex(_two_level(rng, 24, 40, 75, _ffi.METRIC_L2, gen), gpu)
+    q = gen(64)
+    want = _lists(dev, q, 100, _ffi.SEARCH_ROUTE_EXACT_ONLY)
+    os.environ["CUDDLE_ROUTE_MARGIN_HALF"] = "1"
+    try:
+        got = _lists(dev, q, 100)
+        _, _, _, st = dev.search_batch(q, 10, 100, 5, want_stats=True)
+    finally:
+        del os.environ["CUDDLE_ROUTE_MARGIN_HALF"]
+    assert got == want
+    assert st["route_fallbacks"] > 0, st  # one spare candidate cannot absorb the filter's error for every query

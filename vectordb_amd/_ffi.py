@@ -36,6 +36,7 @@ SEARCH_STATS_VARIANT = 0x1
 SEARCH_TIME_STAGES = 0x2
 SEARCH_ROUTE_EXACT_ONLY = 0x4
 SEARCH_ROUTE_GROUPED = 0x8
+SEARCH_ROUTE_SPLIT_FILTER = 0x10
 DESC_DEVICE_ARRAYS = 0x1
 DESC_ADOPT_VECTORS = 0x2
 STAGE_NAMES = ("quantize", "route", "scan", "rerank", "topk", "scan_prep")

@@ -162,8 +162,11 @@ struct Plan {
     float *sel_dist = nullptr;
     // MFMA routing
     uint32_t kc_cap = 0;    // prefilter candidates per query (probes + margin)
+    uint32_t kc_split = 0;  // ... of a level routed with the split-bf16 filter (<= kc_cap)
+    uint32_t kc_half = 0;   // ... of a level routed with the single-pass half-precision filter (<= kc_cap)
     float *qsq = nullptr, *rc_dist = nullptr, *rc_max = nullptr;
-    uint16_t *qcent = nullptr; // centred queries as bf16 (hi, lo) pairs
+    float *qinv = nullptr;     // inverse scale of every query's half-precision row
+    uint16_t *qcent = nullptr; // centred queries as bf16 (hi, lo) pairs, or as scaled fp16
     uint32_t *rc_pos = nullptr, *rflag = nullptr, *rc_cnt = nullptr;
     size_t bytes = 0;
 };
@@ -177,6 +180,9 @@ struct LevelGemm {
     float *sqn = nullptr;      // [n]
     float *mu = nullptr;       // [dim]
     float max_sqn = 0.f;
+    // single-pass half-precision operands (level_table16_kernel), built for levels that can be a whole frontier
+    uint16_t *table16 = nullptr; // [n][split_kp(dim)] scaled fp16
+    float *inv16 = nullptr;      // [n] inverse scales
 };
 
 struct cuddle_index {
@@ -520,6 +526,14 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
             HIP_TRY(hipMemcpy(h.data(), g.sqn, nodes.size() * sizeof(float), hipMemcpyDeviceToHost));
             for (float x : h) g.max_sqn = std::max(g.max_sqn, x);
             g.n = (uint32_t)nodes.size();
+            // every query sees the whole level only if the level above is no wider than probes (and a level wider than
+            // 4096 takes at most 4096 probes)
+            if (l == 0 || level_nodes[l - 1].size() <= 4096) {
+                ST_TRY(dev_alloc(ix, nodes.size() * (size_t)split_kp(D), &g.table16));
+                ST_TRY(dev_alloc(ix, nodes.size(), &g.inv16));
+                hipLaunchKernelGGL(level_table16_kernel, dim3(((uint32_t)nodes.size() + 3) / 4), dim3(256), 0, 0, centroids,
+                                   g.nodes, (uint32_t)nodes.size(), D, split_kp(D), g.mu, reinterpret_cast<_Float16 *>(g.table16), g.inv16);
+            }
         }
     }
 
@@ -647,6 +661,11 @@ static uint32_t route_margin(uint32_t probes) {
     if (const char *e = getenv("CUDDLE_ROUTE_MARGIN")) return (uint32_t)std::max(0, atoi(e));
     return std::max<uint32_t>(24, probes / 8);
 }
+// ... with the single-pass half-precision filter, whose error bound is about 5 (960-d) to 14 (128-d) times the split one's
+static uint32_t route_margin_half(uint32_t probes) {
+    if (const char *e = getenv("CUDDLE_ROUTE_MARGIN_HALF")) return (uint32_t)std::max(0, atoi(e));
+    return std::max<uint32_t>(32, probes / 6);
+}
 
 // Lays the per-chunk arrays of `pl` (strides and qc already set) out from `b`; returns the bytes they take.
 // b == null: sizing only.
@@ -664,7 +683,7 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     size_t o_gd = carve(qc * (size_t)pl.cstride * dist_bytes);
     size_t o_sp = carve(qc * pl.sstride * 4), o_sk = carve(qc * pl.sstride * 4), o_sd = carve(qc * pl.sstride * 4);
     size_t o_sc = carve(qc * 4), o_cc = carve(qc * 4);
-    size_t o_qcent = carve(qc * split_kp(v.dim) * 4), o_qsq = carve(qc * 4);
+    size_t o_qcent = carve(qc * split_kp(v.dim) * 4), o_qsq = carve(qc * 4), o_qinv = carve(qc * 4);
     size_t o_rcp = carve(qc * pl.kc_cap * 4), o_rcd = carve(qc * pl.kc_cap * 4), o_rcm = carve(qc * 4), o_rfl = carve(qc * 4), o_rcc = carve(qc * 4);
     const size_t gw = (size_t)ix->max_parent_width + 1;
     size_t o_pi = carve(qc * pl.probes * 4), o_pp = carve(qc * pl.probes * 4), o_ps = carve(qc * pl.probes * 4), o_pl = carve(qc * pl.probes * 4);
@@ -683,7 +702,7 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     pl.gdist = (uint16_t *)(b + o_gd);
     pl.sel_pos = (uint32_t *)(b + o_sp); pl.sel_key = (uint32_t *)(b + o_sk); pl.sel_dist = (float *)(b + o_sd);
     pl.sel_count = (uint32_t *)(b + o_sc); pl.cand_count = (uint32_t *)(b + o_cc);
-    pl.qcent = (uint16_t *)(b + o_qcent); pl.qsq = (float *)(b + o_qsq);
+    pl.qcent = (uint16_t *)(b + o_qcent); pl.qsq = (float *)(b + o_qsq); pl.qinv = (float *)(b + o_qinv);
     pl.rc_pos = (uint32_t *)(b + o_rcp); pl.rc_dist = (float *)(b + o_rcd); pl.rc_max = (float *)(b + o_rcm);
     pl.rflag = (uint32_t *)(b + o_rfl); pl.rc_cnt = (uint32_t *)(b + o_rcc);
     pl.pair_info = (uint32_t *)(b + o_pi); pl.pair_parent = (uint32_t *)(b + o_pp); pl.pair_sorted = (uint32_t *)(b + o_ps); pl.pair_slot = (uint32_t *)(b + o_pl);
@@ -762,7 +781,9 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
         pl.scan_lds = rabitq_scan_lds_bytes(v.dim, pl.lstride, pl.tcap, pl.dist_cap);
     }
     if (pl.scan_lds > 150 * 1024) return fail(CUDDLE_ERR_UNSUPPORTED, "leaf list of %u slots does not fit the scan kernel's LDS", pl.lstride);
-    pl.kc_cap = (uint32_t)align_up((size_t)pl.probes + route_margin(pl.probes), 4); // every candidate costs an exact distance
+    pl.kc_split = (uint32_t)align_up((size_t)pl.probes + route_margin(pl.probes), 4); // every candidate costs an exact distance
+    pl.kc_half = (uint32_t)align_up((size_t)pl.probes + route_margin_half(pl.probes), 4);
+    pl.kc_cap = std::max(pl.kc_split, pl.kc_half);
     // Chunk size: the per-query rows (above all the spill row of phase-1 distances) times the chunk must fit
     // the budget - the caller's fixed buffer, or kWorkspaceBudget of device memory for the handle's own.
     const size_t budget = fixed_base ? fixed_cap : kWorkspaceBudget;
@@ -865,16 +886,31 @@ static void launch_prefilter(const Plan &pl, uint32_t nq, uint32_t n, uint32_t k
 
 // Approximate distances of every query of the chunk to every node of a level that has contraction
 // operands: pl.fdist[q][0..g.n) and pl.qsq[q].
-static void launch_level_gemm(cuddle_index *ix, const Plan &pl, const LevelGemm &g, const float *dq, uint32_t nq, hipStream_t s) {
+// half: from the single-pass half-precision operands (g.table16 must exist) instead of the split ones.
+static void launch_level_gemm(cuddle_index *ix, const Plan &pl, const LevelGemm &g, const float *dq, uint32_t nq, hipStream_t s,
+                              bool half = false) {
     const IndexDev &v = ix->dev;
     const uint32_t n = g.n;
     const uint32_t kp = split_kp(v.dim);
-    hipLaunchKernelGGL(center_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, kp, pl.qcent, pl.qsq);
     const uint32_t gy = (nq + kGemmBM - 1) / kGemmBM, gx = (n + 63) / 64;
     // XCD row groups: as few as keep an XCD's share of A within half of its 4 MiB L2
     uint32_t rg = 1;
-    while (rg < 8 && (uint64_t)nq * kp * 4 / rg > (2u << 20) && gy >= 2 * rg) rg *= 2;
+    while (rg < 8 && (uint64_t)nq * kp * (half ? 2 : 4) / rg > (2u << 20) && gy >= 2 * rg) rg *= 2;
     const uint32_t rows_per = (gy + rg - 1) / rg, pgroups = 8 / rg;
+    if (half) {
+        hipLaunchKernelGGL(center_queries16_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, kp,
+                           reinterpret_cast<_Float16 *>(pl.qcent), pl.qsq, pl.qinv);
+#define CUDDLE_ROUTE_GEMM16(NT, BK)                                                                                          \
+    hipLaunchKernelGGL((route_gemm16_kernel<NT, BK>), dim3(8 * rows_per * ((gxh + pgroups - 1) / pgroups)), dim3(256),         \
+                       (route_gemm16_lds_bytes<NT, BK>()), s, (const u32x4 *)pl.qcent, pl.qsq, pl.qinv, (const u32x4 *)g.table16, \
+                       g.sqn, g.inv16, nq, n, kp, v.metric, pl.fdist, pl.fstride, gxh, gy, rg)
+        // measured on 1000 x 8682 x 960: K steps of 128 the same within 1 %, 128-wide column tiles 2 % slower
+        const uint32_t gxh = gx;
+        CUDDLE_ROUTE_GEMM16(1, 64);
+#undef CUDDLE_ROUTE_GEMM16
+        return;
+    }
+    hipLaunchKernelGGL(center_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, kp, pl.qcent, pl.qsq);
 #define CUDDLE_ROUTE_GEMM(NT, BK)                                                                                            \
     hipLaunchKernelGGL((route_gemm_kernel<NT, BK>), dim3(8 * rows_per * ((gx + pgroups - 1) / pgroups)), dim3(256),          \
                        (route_gemm_lds_bytes<NT, BK>()), s, (const u32x4 *)pl.qcent, pl.qsq, (const u32x4 *)g.table, g.sqn,  \
@@ -906,6 +942,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
     bool grouped = false; // this level's distances come from the (query, parent) pairs of the level above
     bool have_seg = false; // ... and the grouped queries' frontiers exist as segment tables only (pl.seg[cur])
     static const bool no_filter = getenv("CUDDLE_GROUPED_EXACT") != nullptr; // tuning aid: exact distances for every pair
+    static const bool no_half = getenv("CUDDLE_ROUTE_SPLIT_FILTER") != nullptr; // tuning aid: split-bf16 filter on every level
     // the filter paths end in route_finish_kernel, whose LDS holds the sorted candidates, the expansion scratch and the
     // segment table: with probes in the thousands and a level wider still that passes what a CU has, and the level
     // goes through the exact kernels instead
@@ -950,7 +987,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 // approximate distances of all pairs on the matrix cores, then the same prefilter / exact
                 // refinement / proof as on a shared level, per query; queries that are not grouped (small
                 // frontiers) or fail the proof are flagged for the exact kernels below
-                const uint32_t kp = split_kp(v.dim), kc = std::min(bound, pl.kc_cap);
+                const uint32_t kp = split_kp(v.dim), kc = std::min(bound, pl.kc_split);
                 hipLaunchKernelGGL(center_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, kp, pl.qcent, pl.qsq);
 #define CUDDLE_GROUPED_GEMM(KC)                                                                                              \
     hipLaunchKernelGGL(route_gemm_grouped_kernel<KC>, dim3(items), dim3(256), (route_gemm_grouped_lds_bytes<KC>()), s, v,       \
@@ -1007,8 +1044,9 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         }
         const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound && finish_fits(g.n);
         if (use_gemm) {
-            const uint32_t n = g.n, kc = std::min(n, pl.kc_cap);
-            launch_level_gemm(ix, pl, g, dq, nq, s);
+            const bool half = g.table16 && !(flags & CUDDLE_SEARCH_ROUTE_SPLIT_FILTER) && !no_half;
+            const uint32_t n = g.n, kc = std::min(n, half ? pl.kc_half : pl.kc_split);
+            launch_level_gemm(ix, pl, g, dq, nq, s, half);
             if (n <= 512 * 32)
                 launch_prefilter(pl, nq, n, kc, nullptr, nullptr, nullptr, s);
             else
@@ -1019,7 +1057,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(kc), pl.probes), s,
                                v, g.nodes, n, pl.rc_pos, pl.rc_dist, pl.kc_cap, kc, pl.rc_max, pl.qsq, g.max_sqn, pl.probes,
                                pl.frontier[cur ^ 1], pl.fstride, pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,
-                               pl.rflag, &ix->d_stats->fallbacks, po);
+                               pl.rflag, &ix->d_stats->fallbacks, po, nullptr, nullptr, nullptr, nullptr, half ? 1u : 0u);
             only = pl.rflag; // queries whose selection could not be proven exact fall through to the exact kernels
         }
         // blocks per query of the exact distance kernel (they stride over the frontier): after a filter path only the
@@ -1519,9 +1557,11 @@ extern "C" cuddle_status cuddle_route_filter_error(cuddle_index *idx, const floa
         for (uint32_t q0 = 0; q0 < n_queries; q0 += pl.qc) {
             const uint32_t qc = std::min(pl.qc, n_queries - q0);
             HIP_TRY(hipMemcpy(io.q, queries + (uint64_t)q0 * dim, (size_t)qc * dim * 4, hipMemcpyHostToDevice));
-            launch_level_gemm(idx, pl, g, io.q, qc, nullptr);
+            // the filter a search uses on this level: single-pass half precision where its operands exist
+            const bool half = g.table16 && !getenv("CUDDLE_ROUTE_SPLIT_FILTER");
+            launch_level_gemm(idx, pl, g, io.q, qc, nullptr, half);
             hipLaunchKernelGGL(route_filter_error_kernel, dim3((g.n + 255) / 256, qc), dim3(256), 0, nullptr, idx->dev, io.q, g.nodes, g.n,
-                               pl.fdist, pl.fstride, pl.qsq, g.max_sqn, d_max);
+                               pl.fdist, pl.fstride, pl.qsq, g.max_sqn, d_max, half ? 1u : 0u);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(nullptr));
         }

@@ -979,7 +979,100 @@ center_queries_kernel(const float *queries, const float *mu, uint32_t nq, uint32
     if (lane == 0) sqn[q] = s;
 }
 
+// ---- single-pass half-precision operands (levels every query sees whole) -----------------------
+// A level near the top of the tree is wide compared with probes, its nodes are spread out, and the
+// gap between the probes-th and the (probes + margin)-th distance is large compared with what one
+// rounding of each operand to 11 significant bits costs. There the filter needs one matrix-core
+// product per value pair instead of the split form's three, and half the operand bytes.
+// Every row (query or node) is scaled by its own power of two so that its largest component lands
+// in [2^13, 2^14): then a component is below fp16's normal range only if it is 2^-27 of the row's
+// largest, and whatever the conversion does with it (round to a subnormal: 2^-25, flush: 2^-14 in
+// scaled units) is at most 2^-27 |row|_inf in the row's own units. Per product x y:
+//   |x^ y^ - x y| <= (2^-10 + 2^-22) |x y| + 2^-27 (|x| |b|_inf + |y| |a|_inf) (1 + 2^-11),
+// summed over a row pair: <= (2^-10 + 2^-22) sum|x y| + 2^-26 sqrt(D) |a| |b| (1 + 2^-11); fp16
+// products are exact in f32. route_error_bound(half = 1) collects this as 1.01 * 2^-10.
+
+// The power of two 2^se with m * 2^se in [2^13, 2^14) (m > 0 finite; exponent clamped so that the
+// scale and its inverse are normal floats); m = 0 or not finite: 1.
+__device__ __forceinline__ int half_scale_exp(float m) {
+    if (!(m > 0.f) || !(m < __builtin_inff())) return 0;
+    int e;
+    (void)frexpf(m, &e); // m = f * 2^e, f in [0.5, 1)
+    return max(-120, min(120, 14 - e));
+}
+
+// Row j of the level (see level_table_kernel) minus mu as fp16, scaled; inv[j] = the inverse scale.
+// One wave per row; grid = ceil(n / 4), block 256. table: [n][kp] halfs (kp a multiple of 64, zero padded).
+__global__ void __launch_bounds__(256)
+level_table16_kernel(const float *centroids, const uint32_t *level_nodes, uint32_t n, uint32_t dim, uint32_t kp,
+                     const float *mu, _Float16 *table, float *inv) {
+    const uint32_t j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= n) return;
+    const float *c = centroids + (uint64_t)(level_nodes ? level_nodes[j] : j) * dim;
+    float m = 0.f;
+    for (uint32_t i = lane; i < dim; i += 64) m = fmaxf(m, fabsf(c[i] - mu[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const int se = half_scale_exp(m);
+    const float sc = ldexpf(1.0f, se);
+    _Float16 *t = table + (uint64_t)j * kp;
+    for (uint32_t i = lane; i < kp; i += 64) t[i] = (_Float16)(i < dim ? (c[i] - mu[i]) * sc : 0.f);
+    if (lane == 0) inv[j] = ldexpf(1.0f, -se);
+}
+
+// q' = q - mu as scaled fp16, |q'|^2 (of the f32 values) and the inverse scale, one wave per query.
+__global__ void __launch_bounds__(256)
+center_queries16_kernel(const float *queries, const float *mu, uint32_t nq, uint32_t dim, uint32_t kp, _Float16 *out,
+                        float *sqn, float *inv) {
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const float *src = queries + (uint64_t)q * dim;
+    _Float16 *row = out + (uint64_t)q * kp;
+    float s = 0.f, m = 0.f;
+    const bool vec = (dim & 3) == 0 && (kp & 7) == 0;
+    if (vec) {
+        for (uint32_t i = 4 * lane; i < dim; i += 256) {
+            const float4 x = *reinterpret_cast<const float4 *>(src + i), u = *reinterpret_cast<const float4 *>(mu + i);
+            const float v0 = x.x - u.x, v1 = x.y - u.y, v2 = x.z - u.z, v3 = x.w - u.w;
+            s = __builtin_fmaf(v0, v0, s); s = __builtin_fmaf(v1, v1, s); s = __builtin_fmaf(v2, v2, s); s = __builtin_fmaf(v3, v3, s);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
+        }
+    } else {
+        for (uint32_t i = lane; i < dim; i += 64) {
+            const float v = src[i] - mu[i];
+            s = __builtin_fmaf(v, v, s);
+            m = fmaxf(m, fabsf(v));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        m = fmaxf(m, __shfl_xor(m, o, 64));
+    }
+    const int se = half_scale_exp(m);
+    const float sc = ldexpf(1.0f, se);
+    if (vec) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        for (uint32_t i = 4 * lane; i < kp; i += 256) { // the same lane re-reads what it read above
+            f16x4 o = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            if (i < dim) {
+                const float4 x = *reinterpret_cast<const float4 *>(src + i), u = *reinterpret_cast<const float4 *>(mu + i);
+                o[0] = (_Float16)((x.x - u.x) * sc); o[1] = (_Float16)((x.y - u.y) * sc);
+                o[2] = (_Float16)((x.z - u.z) * sc); o[3] = (_Float16)((x.w - u.w) * sc);
+            }
+            *reinterpret_cast<f16x4 *>(row + i) = o;
+        }
+    } else {
+        for (uint32_t i = lane; i < kp; i += 64) row[i] = (_Float16)(i < dim ? (src[i] - mu[i]) * sc : 0.f);
+    }
+    if (lane == 0) {
+        sqn[q] = s;
+        inv[q] = ldexpf(1.0f, -se);
+    }
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int NT, int BK>
@@ -1120,6 +1213,92 @@ route_gemm_kernel(const u32x4 *A, const float *Asq, const u32x4 *B, const float 
         }
 }
 
+// The contraction from single-pass half-precision operands (level_table16_kernel /
+// center_queries16_kernel): S = (sum_k a^ b^) * ainv * binv on v_mfma_f32_32x32x16_f16, one
+// accumulator per tile, d~ from S and the f32 squared norms as above. Same block tile (128 x 64, 4
+// waves as 2 x 2; NT = 2: 128 x 128), XCD-aware block order and output as route_gemm_kernel; half the operand bytes per
+// K step, so the blocks are lighter (LDS: (128 + 64) rows x (BK / 8 + 1) 16-byte units) and more of
+// them are in flight per CU, which is what a loop bound by the latency of its tile loads needs.
+// kp a multiple of BK.
+template <int NT, int BK>
+constexpr size_t route_gemm16_lds_bytes() { return (size_t)(kGemmBM + 64 * NT) * (BK / 8 + 1) * 16; }
+
+template <int NT, int BK>
+__global__ void __launch_bounds__(256, NT == 1 ? 4 : 3)
+route_gemm16_kernel(const u32x4 *A, const float *Asq, const float *Ainv, const u32x4 *B, const float *Bsq, const float *Binv,
+                    uint32_t M, uint32_t N, uint32_t kp, uint32_t metric, float *out, uint32_t ostride, uint32_t gx, uint32_t gy,
+                    uint32_t rg) {
+    constexpr int BN = 64 * NT, CH = BK / 8, RS = CH + 1, RPP = 256 / CH, PA = kGemmBM / RPP, PB = BN / RPP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *As = reinterpret_cast<u32x4 *>(smem); // [128][RS]
+    u32x4 *Bs = As + kGemmBM * RS;               // [BN][RS]
+    const uint32_t id = blockIdx.x;
+    const uint32_t xcd = id & 7, local = id >> 3, pgroups = 8 / rg, rows_per = (gy + rg - 1) / rg;
+    const uint32_t by = (xcd % rg) * rows_per + local % rows_per, bx = (local / rows_per) * pgroups + xcd / rg;
+    if (bx >= gx || by >= gy) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t wr = w >> 1, wc = w & 1, r = lane & 31, h = lane >> 5;
+    const uint32_t lr = tid / CH, c = tid % CH, rowu = kp / 8; // 16-byte units (8 halfs) per row
+    const u32x4 *ga[PA], *gb[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) ga[i] = A + (uint64_t)min(by * kGemmBM + lr + RPP * i, M - 1) * rowu + c;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) gb[i] = B + (uint64_t)min(bx * BN + lr + RPP * i, N - 1) * rowu + c;
+    u32x4 pa[PA], pb[PB];
+    auto load_tile = [&](uint32_t u0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) pa[i] = ga[i][u0];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) pb[i] = gb[i][u0];
+    };
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+    load_tile(0);
+    for (uint32_t u0 = 0; u0 < rowu; u0 += CH) {
+        __syncthreads(); // previous step's LDS reads are done
+#pragma unroll
+        for (int i = 0; i < PA; ++i) As[(lr + RPP * i) * RS + c] = pa[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) Bs[(lr + RPP * i) * RS + c] = pb[i];
+        __syncthreads();
+        if (u0 + CH < rowu) load_tile(u0 + CH);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const uint32_t g = 2 * ks + h; // this half-wave's 8 of the step's 16 values
+            f16x8 a[2], b[NT];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = __builtin_bit_cast(f16x8, As[(wr * 64 + t * 32 + r) * RS + g]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[t] = __builtin_bit_cast(f16x8, Bs[(wc * 32 * NT + t * 32 + r) * RS + g]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const uint32_t gn = bx * BN + wc * 32 * NT + nt * 32 + r;
+        if (gn >= N) continue;
+        const float bs = Bsq[gn], bi = Binv[gn];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t gm = by * kGemmBM + wr * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (gm >= M) continue;
+                out[(uint64_t)gm * ostride + gn] = approx_distance(metric, (acc[mt][nt][e] * Ainv[gm]) * bi, Asq[gm], bs);
+            }
+    }
+}
+
 // The same contraction for a level whose frontiers differ per query: one block per work item of
 // pair_scan_kernel = a parent node and up to kGroupPairs (64) of the queries that chose it. A rows are
 // gathered by query; B rows are the children's rows of the level table, contiguous because the level
@@ -1228,8 +1407,10 @@ route_gemm_grouped_kernel(IndexDev ix, const u32x4 *A, const float *Asq, const u
 // as ((2.5 D + 64) * 2^-24 + 3.25 * 2^-16) times
 //   L2: |q'|^2 + max|c'|^2      DOT: |q| max|c|      COSINE: 1.
 // (L2: the error of S enters d~ twice, and 2 sum|x_i y_i| <= |q'|^2 + |c'|^2.)
-__device__ __forceinline__ float route_error_bound(uint32_t metric, uint32_t dim, float qsq, float max_csq) {
-    const float cu = (2.5f * (float)dim + 64.0f) * 5.9604645e-8f + 3.25f * 1.52587890625e-5f;
+// half != 0: the single-pass half-precision operands, whose per-product term is 1.01 * 2^-10 instead
+// (see level_table16_kernel; D <= 32768, so 2^-26 sqrt(D) is below a hundredth of 2^-10).
+__device__ __forceinline__ float route_error_bound(uint32_t metric, uint32_t dim, float qsq, float max_csq, uint32_t half = 0) {
+    const float cu = (2.5f * (float)dim + 64.0f) * 5.9604645e-8f + (half ? 1.01f * 9.765625e-4f : 3.25f * 1.52587890625e-5f);
     if (metric == kMetricL2) return cu * (qsq + max_csq);
     if (metric == kMetricDot) return cu * sqrtf(qsq) * sqrtf(max_csq);
     return cu;
@@ -1241,7 +1422,7 @@ __device__ __forceinline__ float route_error_bound(uint32_t metric, uint32_t dim
 // floats, so the unsigned maximum orders them). grid = (ceil(n/256), nq), block 256.
 __global__ void __launch_bounds__(256)
 route_filter_error_kernel(IndexDev ix, const float *queries, const uint32_t *level_nodes, uint32_t n, const float *fdist,
-                          uint32_t fstride, const float *qsq, float max_csq, uint32_t *dmax) {
+                          uint32_t fstride, const float *qsq, float max_csq, uint32_t *dmax, uint32_t half) {
     const uint32_t q = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x, D = ix.dim;
     if (j >= n) return;
     const float *a = queries + (uint64_t)q * D, *b = ix.centroids + (uint64_t)level_nodes[j] * D;
@@ -1258,7 +1439,7 @@ route_filter_error_kernel(IndexDev ix, const float *queries, const uint32_t *lev
     else if (ix.metric == kMetricDot) d = -dot;
     else d = (aa == 0.0 || bb == 0.0) ? 1.0 : 1.0 - dot / (sqrt(aa) * sqrt(bb));
     const float err = (float)fabs((double)fdist[(uint64_t)q * fstride + j] - d);
-    const float bound = route_error_bound(ix.metric, D, qsq[q], max_csq);
+    const float bound = route_error_bound(ix.metric, D, qsq[q], max_csq, half);
     atomicMax(&dmax[0], __float_as_uint(bound > 0.f ? err / bound : (err > 0.f ? 3.4e38f : 0.f)));
     atomicMax(&dmax[1], __float_as_uint(err));
 }
@@ -1428,7 +1609,7 @@ route_finish_kernel(IndexDev ix, const uint32_t *level_nodes, uint32_t n, const 
                     float max_csq, uint32_t probes, uint32_t *next_frontier, uint32_t fstride, uint32_t *next_fcount,
                     uint32_t *leaves, uint32_t lstride, uint32_t *lcount, uint32_t *flag, uint32_t *fallbacks, PairOut po,
                     const uint32_t *ncount = nullptr, const uint32_t *skip = nullptr, const uint32_t *cand_cnt = nullptr,
-                    const uint32_t *seg = nullptr) {
+                    const uint32_t *seg = nullptr, uint32_t half_filter = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t kpad = next_pow2(kc);
     uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);
@@ -1471,7 +1652,7 @@ route_finish_kernel(IndexDev ix, const uint32_t *level_nodes, uint32_t n, const 
     }
     CUDDLE_STAMP(9, 2);
     const float tau = f32_from_key((uint32_t)(skeys[probes - 1] >> 32));
-    const float e = route_error_bound(ix.metric, ix.dim, qsq[q], max_csq);
+    const float e = route_error_bound(ix.metric, ix.dim, qsq[q], max_csq, half_filter);
     const bool ok = kc >= n || (cand_max[q] - e > tau);
     if (!ok) {
         if (tid == 0) {
