@@ -28,7 +28,7 @@ cd "$root"
 python3 tools/pmc_traffic.py $raw/pmc_FETCH_SIZE.csv $raw/pmc_WRITE_SIZE.csv "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py $common --steps 3 --warmup 1 $*" "$cfg" > "$out/pmc_hbm_traffic.json"
 python3 tools/kstats.py "$out/kernel_stats.csv" > "$out/kernel_stats_summary.txt"
 if [ -n "$MFMA" ]; then
-  ctr="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE"
+  ctr="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE"
   cd /tmp
   timeout -s KILL 300 rocprofv3 --pmc $ctr -d $raw/mfma -o p --output-format csv -- python3 "$root/bench.py" $common --steps 3 --warmup 1 "$@" > /dev/null 2>&1
   keep $raw/mfma $raw/pmc_mfma.csv

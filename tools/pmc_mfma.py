@@ -1,10 +1,10 @@
 """Matrix-core utilisation of the library's kernels that issue MFMA instructions, from one rocprofv3
---pmc pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES
-SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE) and the kernel-trace statistics of the same command.
+--pmc pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA
+SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE) and the kernel-trace statistics of the same command.
 
     python tools/pmc_mfma.py counter_collection.csv kernel_stats.csv "<command>" > profiles/r02_<config>_pmc_mfma.json
 
-Per kernel and launch: MFMA instructions, bf16 MFMA flops (MOPS x 512), the share of the kernel's
+Per kernel and launch: MFMA instructions, bf16 + f16 MFMA flops (MOPS x 512; the two types share a peak), the share of the kernel's
 SIMD-cycles in which the MFMA pipe was busy (busy cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs):
 rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs), and flops / average duration against the 2.5 PFLOP/s
 dense bf16 peak."""
@@ -46,10 +46,10 @@ def main():
         mean = {c: v[c] / n[c] for c in v}
         if mean.get("SQ_INSTS_MFMA", 0) <= 0:
             continue
-        flops = mean.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) * 512
+        flops = (mean.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) + mean.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0)) * 512
         gui = mean.get("GRBM_GUI_ACTIVE", 0.0) / XCDS
         e = {"launches": n.get("SQ_INSTS_MFMA", 0), "counters_mean": {c: round(x, 1) for c, x in sorted(mean.items())},
-             "mfma_flops_bf16": flops,
+             "mfma_flops_bf16_f16": flops,
              "mfma_busy_share": (mean.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * SIMDS)) if gui else None}
         if k in dur and dur[k][0]:
             avg_ns = dur[k][1] / dur[k][0]
