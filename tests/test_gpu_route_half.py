@@ -88,9 +88,30 @@ def test_margin_of_one_falls_back_to_the_exact_kernels(gpu):
     want = _lists(dev, q, 100, _ffi.SEARCH_ROUTE_EXACT_ONLY)
     os.environ["CUDDLE_ROUTE_MARGIN_HALF"] = "1"
     try:
+        _, _, _, st = dev.search_batch(q, 10, 100, 5, want_stats=True)  # (the handle's first call: later ones may have learnt)
         got = _lists(dev, q, 100)
-        _, _, _, st = dev.search_batch(q, 10, 100, 5, want_stats=True)
     finally:
         del os.environ["CUDDLE_ROUTE_MARGIN_HALF"]
     assert got == want
     assert st["route_fallbacks"] > 0, st  # one spare candidate cannot absorb the filter's error for every query
+
+
+def test_a_level_whose_proofs_keep_failing_returns_to_the_split_filter(gpu):
+    """With one spare candidate the half-precision proofs fail for many queries; the failures are counted per level,
+    and after the first calls the level is routed with the split filter again: exact lists throughout, and the
+    fallbacks of a late search are those of the split filter (a margin of 24: next to none)."""
+    rng = np.random.default_rng(13)
+    gen = CASES["plain"](rng, 24)
+    dev = DeviceIndex(_two_level(rng, 24, 40, 75, _ffi.METRIC_L2, gen), gpu)
+    q = gen(128)
+    want = _lists(dev, q, 100, _ffi.SEARCH_ROUTE_EXACT_ONLY)
+    os.environ["CUDDLE_ROUTE_MARGIN_HALF"] = "1"
+    try:
+        _, _, _, first = dev.search_batch(q, 10, 100, 5, want_stats=True)
+        for _ in range(6):
+            assert _lists(dev, q, 100) == want
+        _, _, _, late = dev.search_batch(q, 10, 100, 5, want_stats=True)
+    finally:
+        del os.environ["CUDDLE_ROUTE_MARGIN_HALF"]
+    assert first["route_fallbacks"] >= 8, first
+    assert late["route_fallbacks"] * 4 <= first["route_fallbacks"], (first, late)

@@ -210,6 +210,16 @@ struct cuddle_index {
     uint32_t timed_searches = 0;
     hipStream_t last_stream = nullptr;
     bool stream_used = false; // last_stream names the stream of an earlier call
+    // The single-pass half-precision routing filter is judged per level by how often its proof fails: a level whose
+    // queries fall back to the exact kernels too often goes back to the split filter for good (HalfFeedback below).
+    std::vector<uint8_t> half_ok;      // [n_levels] the level may use the half-precision filter
+    std::vector<uint32_t> half_seen;   // [n_levels] failures already judged
+    uint32_t *d_half_fb = nullptr;     // [n_levels] failures counted by route_finish_kernel, never reset
+    uint32_t *h_half_fb = nullptr;     // pinned snapshot of d_half_fb
+    hipEvent_t half_ev = nullptr;      // the snapshot's copy has completed
+    bool half_pending = false;
+    uint64_t half_q_total = 0, half_q_posted = 0, half_q_seen = 0; // queries routed through a half-filtered level
+    uint32_t half_calls = 0;
     uint32_t last_levels = 0;
     // leaf-sharded exact search: the plan of the batch between cuddle_shard_scan and cuddle_shard_finish
     Plan shard_plan;
@@ -220,6 +230,9 @@ struct cuddle_index {
         ws.release();
         io.release();
         if (d_stats) (void)hipFree(d_stats);
+        if (d_half_fb) (void)hipFree(d_half_fb);
+        if (h_half_fb) (void)hipHostFree(h_half_fb);
+        if (half_ev) (void)hipEventDestroy(half_ev);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
     }
 };
@@ -597,6 +610,13 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     if (st != CUDDLE_OK) return st;
     HIP_TRY(hipMalloc((void **)&ix->d_stats, sizeof(DevStats)));
     HIP_TRY(hipMemset(ix->d_stats, 0, sizeof(DevStats)));
+    ix->half_ok.assign(ix->n_levels, 1);
+    ix->half_seen.assign(ix->n_levels, 0);
+    HIP_TRY(hipMalloc((void **)&ix->d_half_fb, std::max<size_t>(ix->n_levels, 1) * 4));
+    HIP_TRY(hipMemset(ix->d_half_fb, 0, std::max<size_t>(ix->n_levels, 1) * 4));
+    HIP_TRY(hipHostMalloc((void **)&ix->h_half_fb, std::max<size_t>(ix->n_levels, 1) * 4, hipHostMallocDefault));
+    memset(ix->h_half_fb, 0, std::max<size_t>(ix->n_levels, 1) * 4);
+    HIP_TRY(hipEventCreateWithFlags(&ix->half_ev, hipEventDisableTiming));
     ST_TRY(scratch_for_device(device_id, &ix->scratch_ptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipGetLastError());
@@ -654,6 +674,11 @@ extern "C" uint64_t cuddle_index_device_bytes(const cuddle_index *idx) {
 // planning the work space
 // ---------------------------------------------------------------------------------------------
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static bool no_half_env() { // tuning aid: split-bf16 filter on every level
+    static const bool v = getenv("CUDDLE_ROUTE_SPLIT_FILTER") != nullptr;
+    return v;
+}
 
 // Extra candidates the MFMA routing filter keeps beyond `probes` (they absorb the rounding error of
 // the norm-expansion distances; too few only costs exact-path fallbacks, never correctness).
@@ -922,14 +947,45 @@ static void launch_level_gemm(cuddle_index *ix, const Plan &pl, const LevelGemm 
 #undef CUDDLE_ROUTE_GEMM
 }
 
+// HalfFeedback. route_finish_kernel counts, per level, the queries whose half-precision selection could not be proven
+// exact. A snapshot of the counts travels to pinned host memory behind the first few routing calls and every 16th one
+// after; a later call that finds the copy complete judges the levels: more than 2 % of the queries routed in between
+// (and at least 4) failed -> the level uses the split filter from then on. Nothing waits for anything.
+static void half_feedback_poll(cuddle_index *ix) {
+    if (!ix->half_pending || hipEventQuery(ix->half_ev) != hipSuccess) return;
+    ix->half_pending = false;
+    const uint64_t dq = ix->half_q_posted - ix->half_q_seen;
+    for (uint32_t l = 0; l < ix->n_levels; ++l) {
+        const uint32_t d = ix->h_half_fb[l] - ix->half_seen[l];
+        if (d >= 4 && (uint64_t)d * 50 > dq) ix->half_ok[l] = 0;
+        ix->half_seen[l] = ix->h_half_fb[l];
+    }
+    ix->half_q_seen = ix->half_q_posted;
+}
+static void half_feedback_post(cuddle_index *ix, uint32_t nq, hipStream_t s) {
+    ix->half_q_total += nq;
+    ix->half_calls++;
+    if (ix->half_pending || !(ix->half_calls <= 4 || ix->half_calls % 16 == 0)) return;
+    if (hipMemcpyAsync(ix->h_half_fb, ix->d_half_fb, (size_t)ix->n_levels * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return;
+    if (hipEventRecord(ix->half_ev, s) != hipSuccess) return;
+    ix->half_pending = true;
+    ix->half_q_posted = ix->half_q_total;
+}
+
 // All tree levels (hierarchical.rs:349-423). Leaves end up in pl.leaves / pl.lcount.
 // A level whose frontier is the same for every query (all earlier levels kept all their nodes)
 // and wider than probes goes through the MFMA contraction + exact refinement; every other level
 // through the exact kernels. Both give the same selection.
+// feedback: the call may enqueue a copy and an event for HalfFeedback (not for callers that must enqueue kernels only).
 static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, uint32_t flags,
-                                  hipStream_t s) {
+                                  hipStream_t s, bool feedback = true) {
     const IndexDev &v = ix->dev;
     const uint32_t stats = (flags & CUDDLE_SEARCH_STATS_VARIANT) ? 1u : 0u;
+    half_feedback_poll(ix);
+    bool used_half = false;
+    auto half_on = [&](uint32_t l) { // the level's filter: single-pass half precision unless told or taught otherwise
+        return ix->lvl[l].table16 && !(flags & CUDDLE_SEARCH_ROUTE_SPLIT_FILTER) && !no_half_env() && ix->half_ok[l];
+    };
     // `shared`: every query's frontier at this level is the level's full node list, in
     // breadth-first order (true while all earlier levels kept all their nodes, search() only:
     // search_with_stats re-orders every level).
@@ -942,7 +998,6 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
     bool grouped = false; // this level's distances come from the (query, parent) pairs of the level above
     bool have_seg = false; // ... and the grouped queries' frontiers exist as segment tables only (pl.seg[cur])
     static const bool no_filter = getenv("CUDDLE_GROUPED_EXACT") != nullptr; // tuning aid: exact distances for every pair
-    static const bool no_half = getenv("CUDDLE_ROUTE_SPLIT_FILTER") != nullptr; // tuning aid: split-bf16 filter on every level
     // the filter paths end in route_finish_kernel, whose LDS holds the sorted candidates, the expansion scratch and the
     // segment table: with probes in the thousands and a level wider still that passes what a CU has, and the level
     // goes through the exact kernels instead
@@ -987,6 +1042,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 // approximate distances of all pairs on the matrix cores, then the same prefilter / exact
                 // refinement / proof as on a shared level, per query; queries that are not grouped (small
                 // frontiers) or fail the proof are flagged for the exact kernels below
+                // (the half-precision operands were measured here too: 170 -> 150 us on a 1M-node level of 128-d rows, slower
+                // on a 100 000-node one - these small contractions are bound by their latencies, not by operand bytes)
                 const uint32_t kp = split_kp(v.dim), kc = std::min(bound, pl.kc_split);
                 hipLaunchKernelGGL(center_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, kp, pl.qcent, pl.qsq);
 #define CUDDLE_GROUPED_GEMM(KC)                                                                                              \
@@ -1044,7 +1101,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         }
         const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound && finish_fits(g.n);
         if (use_gemm) {
-            const bool half = g.table16 && !(flags & CUDDLE_SEARCH_ROUTE_SPLIT_FILTER) && !no_half;
+            const bool half = half_on(l);
+            used_half |= half;
             const uint32_t n = g.n, kc = std::min(n, half ? pl.kc_half : pl.kc_split);
             launch_level_gemm(ix, pl, g, dq, nq, s, half);
             if (n <= 512 * 32)
@@ -1057,7 +1115,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(kc), pl.probes), s,
                                v, g.nodes, n, pl.rc_pos, pl.rc_dist, pl.kc_cap, kc, pl.rc_max, pl.qsq, g.max_sqn, pl.probes,
                                pl.frontier[cur ^ 1], pl.fstride, pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,
-                               pl.rflag, &ix->d_stats->fallbacks, po, nullptr, nullptr, nullptr, nullptr, half ? 1u : 0u);
+                               pl.rflag, &ix->d_stats->fallbacks, po, nullptr, nullptr, nullptr, nullptr, half ? 1u : 0u,
+                               half ? ix->d_half_fb + l : nullptr);
             only = pl.rflag; // queries whose selection could not be proven exact fall through to the exact kernels
         }
         // blocks per query of the exact distance kernel (they stride over the frontier): after a filter path only the
@@ -1105,6 +1164,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
     if (stats) // what is left below the last level: empty, the frontier on which the reference's loop ends
         HIP_TRY(hipMemcpyAsync(pl.level_fc + (size_t)ix->n_levels * pl.qc, pl.fcount[cur], (size_t)nq * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipGetLastError());
+    if (used_half && feedback) half_feedback_post(ix, nq, s);
     return CUDDLE_OK;
 }
 
@@ -1206,7 +1266,7 @@ static cuddle_status search_device_locked(cuddle_index *ix, const float *dq, uin
         mark(ix, s, CUDDLE_STAGE_QUANTIZE);
         ST_TRY(launch_quantize(ix, pl, q, qc, s));
         mark(ix, s, CUDDLE_STAGE_ROUTE);
-        ST_TRY(launch_route(ix, pl, q, qc, flags, s));
+        ST_TRY(launch_route(ix, pl, q, qc, flags, s, fixed_ws == nullptr));
         mark(ix, s, CUDDLE_STAGE_SCAN);
         ST_TRY(launch_scan_select(ix, pl, qc, s));
         mark(ix, s, CUDDLE_STAGE_RERANK);
@@ -1558,7 +1618,7 @@ extern "C" cuddle_status cuddle_route_filter_error(cuddle_index *idx, const floa
             const uint32_t qc = std::min(pl.qc, n_queries - q0);
             HIP_TRY(hipMemcpy(io.q, queries + (uint64_t)q0 * dim, (size_t)qc * dim * 4, hipMemcpyHostToDevice));
             // the filter a search uses on this level: single-pass half precision where its operands exist
-            const bool half = g.table16 && !getenv("CUDDLE_ROUTE_SPLIT_FILTER");
+            const bool half = g.table16 && !no_half_env() && idx->half_ok[level];
             launch_level_gemm(idx, pl, g, io.q, qc, nullptr, half);
             hipLaunchKernelGGL(route_filter_error_kernel, dim3((g.n + 255) / 256, qc), dim3(256), 0, nullptr, idx->dev, io.q, g.nodes, g.n,
                                pl.fdist, pl.fstride, pl.qsq, g.max_sqn, d_max, half ? 1u : 0u);

@@ -1609,7 +1609,7 @@ route_finish_kernel(IndexDev ix, const uint32_t *level_nodes, uint32_t n, const 
                     float max_csq, uint32_t probes, uint32_t *next_frontier, uint32_t fstride, uint32_t *next_fcount,
                     uint32_t *leaves, uint32_t lstride, uint32_t *lcount, uint32_t *flag, uint32_t *fallbacks, PairOut po,
                     const uint32_t *ncount = nullptr, const uint32_t *skip = nullptr, const uint32_t *cand_cnt = nullptr,
-                    const uint32_t *seg = nullptr, uint32_t half_filter = 0) {
+                    const uint32_t *seg = nullptr, uint32_t half_filter = 0, uint32_t *half_fallbacks = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t kpad = next_pow2(kc);
     uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);
@@ -1658,6 +1658,7 @@ route_finish_kernel(IndexDev ix, const uint32_t *level_nodes, uint32_t n, const 
         if (tid == 0) {
             flag[q] = 1;
             atomicAdd(fallbacks, 1u);
+            if (half_fallbacks) atomicAdd(half_fallbacks, 1u); // this level's count, never reset: the host judges the filter by it
         }
         return;
     }
