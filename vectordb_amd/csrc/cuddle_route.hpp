@@ -521,11 +521,11 @@ route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride,
             __syncthreads();
         } else {
             uint32_t keys[KPT];
+            float kv[KPT]; // all loads first (see route_prefilter_reg_kernel); n > scap >= 1 here
 #pragma unroll
-            for (int t = 0; t < KPT; ++t) {
-                const uint32_t i = t * THREADS + tid;
-                keys[t] = i < n ? f32_key(fd[i]) : 0xFFFFFFFFu;
-            }
+            for (int t = 0; t < KPT; ++t) kv[t] = fd[min((uint32_t)t * THREADS + tid, n - 1)];
+#pragma unroll
+            for (int t = 0; t < KPT; ++t) keys[t] = (uint32_t)t * THREADS + tid < n ? f32_key(kv[t]) : 0xFFFFFFFFu;
             if (tid < 2) misc[2 + tid] = 0; // winner counter, tie counter (visible after the barriers inside the select)
             CUDDLE_STAMP(3, 1);
             uint32_t want;
@@ -1488,11 +1488,13 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
     }
     const float *fd = fdist + (uint64_t)q * fstride;
     uint32_t keys[KPT];
+    // every load is issued before the first value is used (a load behind a condition is waited for on its own: twenty
+    // trips to the L2, one after the other); positions past the frontier re-read its last key and are masked afterwards
+    float kv[KPT];
 #pragma unroll
-    for (int t = 0; t < KPT; ++t) {
-        const uint32_t i = t * THREADS + tid;
-        keys[t] = i < n ? f32_key(fd[i]) : 0xFFFFFFFFu;
-    }
+    for (int t = 0; t < KPT; ++t) kv[t] = fd[min((uint32_t)t * THREADS + tid, n - 1)];
+#pragma unroll
+    for (int t = 0; t < KPT; ++t) keys[t] = (uint32_t)t * THREADS + tid < n ? f32_key(kv[t]) : 0xFFFFFFFFu;
     if (tid < 3) misc[1 + tid] = 0; // shortlist and winner counters (visible after the barriers inside the select)
     uint32_t *cp = cand_pos + (uint64_t)q * cstride;
     CUDDLE_STAMP(8, 0);
