@@ -1045,9 +1045,15 @@ scan_tables_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const 
     if (q >= nq) return;
     const uint32_t mine = cand_count[q];
     uint32_t before = 0;
-    for (uint32_t j = lane; j < nq; j += 64) {
-        const uint32_t c = cand_count[j];
-        before += (c > mine || (c == mine && j < q)) ? 1u : 0u;
+    for (uint32_t j0 = lane; j0 < nq; j0 += 64 * 8) { // eight loads in flight per lane (nq >= 1: q < nq)
+        uint32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = cand_count[min(j0 + 64 * u, nq - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t j = j0 + 64 * u;
+            before += (j < nq && (c[u] > mine || (c[u] == mine && j < q))) ? 1u : 0u;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
@@ -1289,13 +1295,19 @@ topk_kernel(IndexDev ix, const uint32_t *sel_pos, const uint32_t *sel_key, const
     const uint32_t npad = next_pow2(max(n, 1u));
     const uint32_t *sp = sel_pos + (uint64_t)q * sel_stride, *sk = sel_key + (uint64_t)q * sel_stride;
     const float *sd = sel_dist + (uint64_t)q * sel_stride;
-    for (uint32_t i = tid; i < npad; i += blockDim.x) {
-        uint64_t key = ~0ull;
-        if (i < n) {
-            uint32_t mid = key_is_rank ? 0u : (sk[i] & 0xFFFFu);
-            key = ((uint64_t)f32_key(sd[i]) << 30) | ((uint64_t)mid << 14) | i;
+    const uint32_t last = max(n, 1u) - 1;
+    for (uint32_t i0 = tid; i0 < npad; i0 += 4 * blockDim.x) { // four entries per thread and trip to memory
+        float dv[4];
+        uint32_t kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dv[u] = sd[min(i0 + u * blockDim.x, last)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kv[u] = key_is_rank ? 0u : (sk[min(i0 + u * blockDim.x, last)] & 0xFFFFu);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * blockDim.x;
+            if (i < npad) skeys[i] = i < n ? (((uint64_t)f32_key(dv[u]) << 30) | ((uint64_t)kv[u] << 14) | i) : ~0ull;
         }
-        skeys[i] = key;
     }
     __syncthreads();
     block_bitonic_sort_u64(skeys, npad);
@@ -1351,14 +1363,24 @@ topk_wave_kernel(IndexDev ix, const uint32_t *sel_pos, const uint32_t *sel_key, 
     const uint32_t *sp = sel_pos + (uint64_t)q * sel_stride, *sk = sel_key + (uint64_t)q * sel_stride;
     const float *sd = sel_dist + (uint64_t)q * sel_stride;
     uint64_t keys[KPL];
+    // every load is issued before the first value is used (loads behind a per-element condition are waited for one by
+    // one); slots past the selection re-read its last entry and are masked afterwards
+    const uint32_t last = max(n, 1u) - 1;
+    float dv[KPL];
+    uint32_t kv[KPL];
+#pragma unroll
+    for (int t = 0; t < KPL; ++t) dv[t] = sd[min((uint32_t)t * 64 + lane, last)];
+    if (!key_is_rank) {
+#pragma unroll
+        for (int t = 0; t < KPL; ++t) kv[t] = sk[min((uint32_t)t * 64 + lane, last)] & 0xFFFFu;
+    } else {
+#pragma unroll
+        for (int t = 0; t < KPL; ++t) kv[t] = 0u;
+    }
 #pragma unroll
     for (int t = 0; t < KPL; ++t) {
         const uint32_t i = t * 64 + lane;
-        keys[t] = ~0ull;
-        if (i < n) {
-            const uint32_t mid = key_is_rank ? 0u : (sk[i] & 0xFFFFu);
-            keys[t] = ((uint64_t)f32_key(sd[i]) << 30) | ((uint64_t)mid << 14) | i;
-        }
+        keys[t] = i < n ? (((uint64_t)f32_key(dv[t]) << 30) | ((uint64_t)kv[t] << 14) | i) : ~0ull;
     }
     const uint32_t nout = min(n, k); // k <= 64: lane r keeps the r-th winner
     uint64_t mine = ~0ull;
