@@ -115,3 +115,30 @@ def test_a_level_whose_proofs_keep_failing_returns_to_the_split_filter(gpu):
         del os.environ["CUDDLE_ROUTE_MARGIN_HALF"]
     assert first["route_fallbacks"] >= 8, first
     assert late["route_fallbacks"] * 4 <= first["route_fallbacks"], (first, late)
+
+
+@pytest.mark.parametrize("metric", [_ffi.METRIC_L2, _ffi.METRIC_DOT, _ffi.METRIC_COSINE])
+def test_half_filter_on_per_query_frontiers(gpu, metric):
+    """A level of per-query frontiers (the 100 x 70 children of the chosen nodes) is contracted from half-precision
+    operands when its table is too large for the Infinity Cache; with that size set to zero a small tree takes the
+    path: the lists must be the split filter's and the exact kernels'."""
+    import torch
+
+    from vectordb_amd.synthetic import build_tree_index_on_device
+
+    os.environ["CUDDLE_GROUPED_HALF_MIN_BYTES"] = "0"
+    try:
+        dti, queries = build_tree_index_on_device(40, 70, 3, 3, torch.device("cuda", gpu), seed=21, n_queries=96, metric=metric,
+                                                  style="gauss")
+        dev = dti.create(gpu)
+        q = queries.cpu().numpy()
+        want = _lists(dev, q, 100, _ffi.SEARCH_ROUTE_EXACT_ONLY)
+        got = _lists(dev, q, 100)
+        got_split = _lists(dev, q, 100, _ffi.SEARCH_ROUTE_SPLIT_FILTER)
+        ids, dist, cnt, st = dev.search_batch(q, 10, 100, 5, want_stats=True)
+        ids_x, dist_x, cnt_x = dev.search_batch(q, 10, 100, 5, _ffi.SEARCH_ROUTE_EXACT_ONLY)
+    finally:
+        del os.environ["CUDDLE_GROUPED_HALF_MIN_BYTES"]
+    assert got == want
+    assert got_split == want
+    assert np.array_equal(ids, ids_x) and np.array_equal(dist.view(np.uint32), dist_x.view(np.uint32)) and np.array_equal(cnt, cnt_x)

@@ -241,6 +241,13 @@ static constexpr uint32_t kMaxChunk = 4096;
 static constexpr size_t kWorkspaceBudget = 3ull << 30; // the handle's work space: chunks shrink before it grows beyond this
 static constexpr size_t kMaxEvents = 1u << 18; // stage-timing events kept between two cuddle_stage_times() calls
 static constexpr uint32_t kScanThreads = 512;
+// Split-table size above which a level of per-query frontiers is contracted from half-precision operands: the
+// 256 MiB Infinity Cache (CUDDLE_GROUPED_HALF_MIN_BYTES overrides it: tests force the path on small trees).
+static uint64_t grouped_half_min_bytes() {
+    const char *e = getenv("CUDDLE_GROUPED_HALF_MIN_BYTES"); // (read at every call: a test sets it for one index)
+    return e ? strtoull(e, nullptr, 10) : (256ull << 20);
+}
+
 static constexpr uint32_t kGemmMinWidth = 512; // narrower levels are routed by the exact kernel
 static constexpr uint32_t kMaxLeafVectors = 4096u * 64u; // the scan's tile tables hold the tile number inside a leaf in 12 bits
 static constexpr uint32_t kMaxCandidates = 1u << 25;    // ... and a tile's scan position in 25 bits
@@ -540,8 +547,9 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
             for (float x : h) g.max_sqn = std::max(g.max_sqn, x);
             g.n = (uint32_t)nodes.size();
             // every query sees the whole level only if the level above is no wider than probes (and a level wider than
-            // 4096 takes at most 4096 probes)
-            if (l == 0 || level_nodes[l - 1].size() <= 4096) {
+            // 4096 takes at most 4096 probes); a level of per-query frontiers gets them when its split table is too large
+            // for the Infinity Cache
+            if (l == 0 || level_nodes[l - 1].size() <= 4096 || nodes.size() * (uint64_t)split_kp(D) * 4 > grouped_half_min_bytes()) {
                 ST_TRY(dev_alloc(ix, nodes.size() * (size_t)split_kp(D), &g.table16));
                 ST_TRY(dev_alloc(ix, nodes.size(), &g.inv16));
                 hipLaunchKernelGGL(level_table16_kernel, dim3(((uint32_t)nodes.size() + 3) / 4), dim3(256), 0, 0, centroids,
@@ -1024,7 +1032,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             continue;
         }
         const uint32_t *only = nullptr;
-        bool grouped_filter = false, grouped_finish = false;
+        bool grouped_filter = false, grouped_finish = false, grouped_half = false;
         uint32_t grouped_kc = 0;
         if (grouped) {
             // pairs recorded by the level above -> parent order -> one block per (parent, 8 queries)
@@ -1042,9 +1050,22 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 // approximate distances of all pairs on the matrix cores, then the same prefilter / exact
                 // refinement / proof as on a shared level, per query; queries that are not grouped (small
                 // frontiers) or fail the proof are flagged for the exact kernels below
-                // (the half-precision operands were measured here too: 170 -> 150 us on a 1M-node level of 128-d rows, slower
-                // on a 100 000-node one - these small contractions are bound by their latencies, not by operand bytes)
-                const uint32_t kp = split_kp(v.dim), kc = std::min(bound, pl.kc_split);
+                // half-precision operands where the contraction streams the level's table from HBM (it exists only for
+                // such levels, see grouped_half_min_bytes): measured 170 -> 132 us on a 1M-node level of 128-d rows; where
+                // the table stays on the die the split operands are as fast and need fewer exact distances
+                grouped_half = half_on(l) && (uint64_t)g.n * split_kp(v.dim) * 4 > grouped_half_min_bytes();
+                used_half |= grouped_half;
+                const uint32_t kp = split_kp(v.dim), kc = std::min(bound, grouped_half ? pl.kc_half : pl.kc_split);
+                if (grouped_half) {
+                    hipLaunchKernelGGL(center_queries16_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, kp,
+                                       reinterpret_cast<_Float16 *>(pl.qcent), pl.qsq, pl.qinv);
+#define CUDDLE_GROUPED_GEMM16(KC)                                                                                            \
+    hipLaunchKernelGGL(route_gemm16_grouped_kernel<KC>, dim3(items), dim3(256), (route_gemm16_grouped_lds_bytes<KC>()), s, v,   \
+                       (const u32x4 *)pl.qcent, pl.qsq, pl.qinv, (const u32x4 *)g.table16, g.sqn, g.inv16, kp, wprev,           \
+                       pl.grp_ioff, reinterpret_cast<const uint4 *>(pl.grp_item), pl.pair_sorted, pl.fdist, pl.fstride)
+                    CUDDLE_GROUPED_GEMM16(64); // K chunk: 32 within 1 %, 128 slower
+#undef CUDDLE_GROUPED_GEMM16
+                } else {
                 hipLaunchKernelGGL(center_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, dq, g.mu, nq, v.dim, kp, pl.qcent, pl.qsq);
 #define CUDDLE_GROUPED_GEMM(KC)                                                                                              \
     hipLaunchKernelGGL(route_gemm_grouped_kernel<KC>, dim3(items), dim3(256), (route_gemm_grouped_lds_bytes<KC>()), s, v,       \
@@ -1052,6 +1073,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                        reinterpret_cast<const uint4 *>(pl.grp_item), pl.pair_sorted, pl.fdist, pl.fstride)
                 CUDDLE_GROUPED_GEMM(64); // K chunk: 32 and 64 measured alike, 128 slower (fewer blocks in flight)
 #undef CUDDLE_GROUPED_GEMM
+                }
                 launch_prefilter(pl, nq, bound, kc, pl.fcount[cur], pl.small_flag, pl.rc_cnt, s);
                 hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256),
                                    (((size_t)v.dim + 3) & ~(size_t)3) * sizeof(float) + (have_seg ? seg_stride(pl.probes) * 4 : 0), s, v, dq,
@@ -1094,7 +1116,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                                v, pl.frontier[cur], bound, pl.rc_pos, pl.rc_dist, pl.kc_cap, grouped_kc, pl.rc_max, pl.qsq, g.max_sqn,
                                pl.probes, pl.frontier[cur ^ 1], pl.fstride, pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,
                                pl.rflag, &ix->d_stats->fallbacks, po, pl.fcount[cur], pl.small_flag, pl.rc_cnt,
-                               have_seg ? pl.seg[cur] : nullptr);
+                               have_seg ? pl.seg[cur] : nullptr, grouped_half ? 1u : 0u, grouped_half ? ix->d_half_fb + l : nullptr);
             if (have_seg) // queries that failed the proof go on through the kernels that walk whole frontiers
                 hipLaunchKernelGGL(route_materialise_kernel, dim3(nq), dim3(256), seg_stride(pl.probes) * 4, s, v, pl.seg[cur], pl.probes,
                                    pl.rflag, pl.small_flag, pl.frontier[cur], pl.fstride, pl.fcount[cur]);

@@ -1400,6 +1400,93 @@ route_gemm_grouped_kernel(IndexDev ix, const u32x4 *A, const float *Asq, const u
     CUDDLE_STAMP(7, 4);
 }
 
+// route_gemm_grouped_kernel from the single-pass half-precision operands (center_queries16_kernel /
+// level_table16_kernel): one matrix-core product per value pair, half the bytes per row. Same work items, same
+// output places.
+template <int KC>
+constexpr size_t route_gemm16_grouped_lds_bytes() { return (size_t)2 * 64 * (KC / 8 + 1) * 16; }
+
+template <int KC>
+__global__ void __launch_bounds__(256, 2)
+route_gemm16_grouped_kernel(IndexDev ix, const u32x4 *A, const float *Asq, const float *Ainv, const u32x4 *B, const float *Bsq,
+                            const float *Binv, uint32_t kp, uint32_t n_parents, const uint32_t *ioff, const uint4 *items,
+                            const uint32_t *sorted, float *fdist, uint32_t fstride) {
+    constexpr int CHU = KC / 8, RS = CHU + 1, U = CHU / 4; // 16-byte units per chunk row; LDS row stride; units per thread
+    static_assert(CHU % 4 == 0, "four threads share a row");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *As = reinterpret_cast<u32x4 *>(smem); // [64][RS]
+    u32x4 *Bs = As + 64 * RS;                    // [64][RS]
+    __shared__ uint32_t pk[64];
+    __shared__ float pasq[64], painv[64]; // squared norms and inverse scales of the pairs' queries
+    const uint32_t item = blockIdx.x;
+    const uint32_t n_items = ioff[n_parents];
+    const uint4 rec = items[min(item, max(n_items, 1u) - 1)];
+    if (item >= n_items) return;
+    const uint32_t pb = rec.x, np = rec.y, cpos0 = rec.z, cc = rec.w; // (pair_scan_kernel's contraction form)
+    if (cc == 0) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t wr = w >> 1, wc = w & 1, r = lane & 31, h = lane >> 5;
+    const uint32_t lrow = tid >> 2, lu = tid & 3, rowu = kp / 8, nchunks = kp / KC;
+    const uint32_t mypair = sorted[pb + min(lrow, np - 1)]; // unused rows repeat the last pair
+    if (lu == 0) {
+        pk[lrow] = mypair;
+        pasq[lrow] = Asq[mypair >> kPairOffBits];
+        painv[lrow] = Ainv[mypair >> kPairOffBits];
+    }
+    const u32x4 *ga = A + (uint64_t)(mypair >> kPairOffBits) * rowu + lu;
+    const u32x4 *Bp = B + (uint64_t)cpos0 * rowu + lu;
+    u32x4 pa[U], pbv[U];
+    const uint32_t ntiles = (cc + 63) / 64, steps = ntiles * nchunks;
+    auto fetch = [&](uint32_t step) { // step = column tile * nchunks + chunk
+        const uint32_t bx = step / nchunks, ch = step - bx * nchunks;
+        const u32x4 *gb = Bp + (uint64_t)min(bx * 64 + lrow, cc - 1) * rowu + ch * CHU;
+#pragma unroll
+        for (int j = 0; j < U; ++j) pbv[j] = gb[4 * j];
+        if (nchunks > 1 || step == 0) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) pa[j] = ga[ch * CHU + 4 * j];
+        }
+    };
+    f32x16 acc;
+    fetch(0);
+    for (uint32_t step = 0; step < steps; ++step) {
+        const uint32_t bx = step / nchunks, ch = step - bx * nchunks;
+        if (ch == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        }
+        __syncthreads(); // the previous step's LDS reads are done (first step: pk written)
+#pragma unroll
+        for (int j = 0; j < U; ++j) Bs[lrow * RS + lu + 4 * j] = pbv[j];
+        if (nchunks > 1 || step == 0) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) As[lrow * RS + lu + 4 * j] = pa[j];
+        }
+        __syncthreads();
+        if (step + 1 < steps) fetch(step + 1);
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const uint32_t g = 2 * ks + h;
+            const f16x8 a = __builtin_bit_cast(f16x8, As[(wr * 32 + r) * RS + g]);
+            const f16x8 b = __builtin_bit_cast(f16x8, Bs[(wc * 32 + r) * RS + g]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+        }
+        if (ch + 1 == nchunks) { // the tile is complete: C/D layout col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+            const uint32_t gn = bx * 64 + wc * 32 + r;
+            if (gn < cc) {
+                const float bs = Bsq[cpos0 + gn], bi = Binv[cpos0 + gn];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t prow = wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (prow >= np) continue;
+                    const uint32_t v = pk[prow], q = v >> kPairOffBits, off = v & ((1u << kPairOffBits) - 1);
+                    fdist[(uint64_t)q * fstride + off + gn] = approx_distance(ix.metric, (acc[e] * painv[prow]) * bi, pasq[prow], bs);
+                }
+            }
+        }
+    }
+}
+
 // Bound on |d~ - d| (d = the exact-order f32 distance) for one query against any node of the
 // level: any-order f32 dot products of length D are within gamma_D * sum|x_i y_i| of the true
 // value, the exact-order L2 within gamma_(D/16+8) of it, centring adds u-relative component
