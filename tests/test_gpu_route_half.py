@@ -142,3 +142,31 @@ def test_half_filter_on_per_query_frontiers(gpu, metric):
     assert got == want
     assert got_split == want
     assert np.array_equal(ids, ids_x) and np.array_equal(dist.view(np.uint32), dist_x.view(np.uint32)) and np.array_equal(cnt, cnt_x)
+
+
+def test_failed_half_proofs_on_per_query_frontiers_take_the_exact_path(gpu):
+    """The same level with one spare candidate: most proofs fail, the queries are re-routed by the exact kernels from
+    their segment tables (lists still exact), and the level then returns to the split filter."""
+    import torch
+
+    from vectordb_amd.synthetic import build_tree_index_on_device
+
+    os.environ["CUDDLE_GROUPED_HALF_MIN_BYTES"] = "0"
+    os.environ["CUDDLE_ROUTE_MARGIN_HALF"] = "1"
+    try:
+        dti, queries = build_tree_index_on_device(40, 70, 3, 3, torch.device("cuda", gpu), seed=22, n_queries=128,
+                                                  metric=_ffi.METRIC_L2, style="gauss")
+        dev = dti.create(gpu)
+        q = queries.cpu().numpy()
+        _, _, _, first = dev.search_batch(q, 10, 100, 5, want_stats=True)
+        want = _lists(dev, q, 100, _ffi.SEARCH_ROUTE_EXACT_ONLY)
+        for _ in range(5):
+            assert _lists(dev, q, 100) == want
+        ids, dist, cnt, late = dev.search_batch(q, 10, 100, 5, want_stats=True)
+        ids_x, dist_x, cnt_x = dev.search_batch(q, 10, 100, 5, _ffi.SEARCH_ROUTE_EXACT_ONLY)
+    finally:
+        del os.environ["CUDDLE_GROUPED_HALF_MIN_BYTES"]
+        del os.environ["CUDDLE_ROUTE_MARGIN_HALF"]
+    assert first["route_fallbacks"] >= 8, first
+    assert late["route_fallbacks"] * 4 <= first["route_fallbacks"], (first, late)
+    assert np.array_equal(ids, ids_x) and np.array_equal(dist.view(np.uint32), dist_x.view(np.uint32)) and np.array_equal(cnt, cnt_x)

@@ -164,6 +164,12 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `make -C vectordb_amd/csrc` "
                 "(or __graft_entry__.build()). There is no CPU fallback."
             )
+        # torch ships its own copy of the HIP runtime under the system's soname; the copy loaded first serves the whole
+        # process, and torch finds the GPU only through its own - so where torch is installed it goes first
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
