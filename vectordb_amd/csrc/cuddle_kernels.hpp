@@ -1271,12 +1271,14 @@ rerank_kernel(IndexDev ix, const float *queries, const uint32_t *sel_pos, uint32
     for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) qs[i] = qg[i];
     __syncthreads();
     const uint32_t j = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
-    const bool act = j < n;
-    const uint32_t pos = sel_pos[(uint64_t)q * sel_stride + (act ? j : 0)];
+    // a group past the selection does nothing: its four lanes leave together, so the quad exchanges of the groups
+    // that stay are among active lanes only (and it reads no row)
+    if (j >= n) return;
+    const uint32_t pos = sel_pos[(uint64_t)q * sel_stride + j];
     const bool vec = (D & 3) == 0;
     float d = distance_group4_qn(qs, ix.vectors + (uint64_t)pos * D, D, ix.metric, sub, vec,
                                  ix.metric == kMetricCosine ? qnorm[q] : 0.f);
-    if (act && sub == 0) sel_dist[(uint64_t)q * sel_stride + j] = d;
+    if (sub == 0) sel_dist[(uint64_t)q * sel_stride + j] = d;
 }
 
 // finalize_results: ascending by (distance, phase-1 order). For the Hamming path phase-1 order is

@@ -1672,12 +1672,12 @@ route_refine_kernel(IndexDev ix, const float *queries, const uint32_t *level_nod
         for (uint32_t i = threadIdx.x; i < seg_stride(pstride); i += blockDim.x) st[i] = seg[(uint64_t)q * seg_stride(pstride) + i];
     __syncthreads();
     const uint32_t j = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
-    const bool act = j < kc;
-    const uint32_t cpos = cand_pos[(uint64_t)q * cstride + (act ? j : 0)];
+    if (j >= kc) return; // (whole 4-lane groups leave: see rerank_kernel)
+    const uint32_t cpos = cand_pos[(uint64_t)q * cstride + j];
     const uint32_t node = seg ? frontier_node(ix, st, pstride, cpos) : level_nodes[cpos];
     float d = distance_group4_qn(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, (D & 3) == 0,
                                  ix.metric == kMetricCosine ? qnorm[q] : 0.f);
-    if (act && sub == 0) cand_dist[(uint64_t)q * cstride + j] = d;
+    if (sub == 0) cand_dist[(uint64_t)q * cstride + j] = d;
 }
 
 inline size_t route_finish_lds_bytes(uint32_t kpad, uint32_t probes) { // keys, expansion scratch, segment table
