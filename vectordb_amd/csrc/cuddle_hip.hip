@@ -1145,8 +1145,11 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         // (rare) flagged queries do work there; after the exact grouped path only the small frontiers; a per-query
         // level that was not worth grouping has, typically, frontiers of fewer than 256 nodes whatever the bound says
         // (and blocks that find nothing to do still cost their dispatch); a shared level's width is known
+        // (a per-query level that was not worth grouping: about 8192 blocks in all - 8 per query for a batch of 1000,
+        // 2 for one of 4096, where dispatching 32 768 mostly idle blocks cost more than the few wide frontiers gain)
+        const uint32_t small_gx = std::max<uint32_t>(2, std::min<uint32_t>(8, 8192 / std::max<uint32_t>(nq, 1)));
         const uint32_t dist_gx = (use_gemm || grouped_filter) ? 1 : grouped ? 4
-                                 : std::min<uint32_t>((bound + 63) / 64, (shared || (flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY)) ? 64 : 8);
+                                 : std::min<uint32_t>((bound + 63) / 64, (shared || (flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY)) ? 64 : small_gx);
         if (!keep_all)
             hipLaunchKernelGGL(route_dist_kernel, dim3(dist_gx, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                pl.frontier[cur], pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, only, pl.qnorm);
