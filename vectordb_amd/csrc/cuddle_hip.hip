@@ -1039,9 +1039,12 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             const uint32_t wprev = ix->level_width[l - 1], total = nq * pl.probes;
             grouped_filter = !stats && g.n && bound <= 512 * 32 && !no_filter && finish_fits(bound);
             const uint32_t nb = (wprev + kPairScanChunk - 1) / kPairScanChunk; // pl.grp_fill: 2 * nb block sums / offsets
-            hipLaunchKernelGGL(pair_block_sums_kernel, dim3(nb), dim3(256), 0, s, pl.grp_cnt, wprev, pl.grp_fill, nb);
-            hipLaunchKernelGGL(pair_block_scan_kernel, dim3(1), dim3(1024), 0, s, pl.grp_fill, nb, wprev, pl.grp_poff, pl.grp_ioff);
-            hipLaunchKernelGGL(pair_scan_kernel, dim3(nb), dim3(256), 0, s, pl.grp_cnt, wprev, pl.grp_fill, nb, pl.grp_poff, pl.grp_ioff,
+            const bool self_carry = nb <= 16; // few chunks: pair_scan_kernel sums the chunks before its own itself
+            if (!self_carry) {
+                hipLaunchKernelGGL(pair_block_sums_kernel, dim3(nb), dim3(256), 0, s, pl.grp_cnt, wprev, pl.grp_fill, nb);
+                hipLaunchKernelGGL(pair_block_scan_kernel, dim3(1), dim3(1024), 0, s, pl.grp_fill, nb, wprev, pl.grp_poff, pl.grp_ioff);
+            }
+            hipLaunchKernelGGL(pair_scan_kernel, dim3(nb), dim3(256), 0, s, pl.grp_cnt, wprev, self_carry ? nullptr : pl.grp_fill, nb, pl.grp_poff, pl.grp_ioff,
                                reinterpret_cast<uint4 *>(pl.grp_item), grouped_filter ? ix->lvl[l - 1].child_rows : nullptr);
             hipLaunchKernelGGL(pair_fill_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pl.pair_info, pl.pair_parent, pl.pair_slot,
                                total, pl.grp_poff, pl.pair_sorted);

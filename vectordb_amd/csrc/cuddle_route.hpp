@@ -671,7 +671,45 @@ pair_scan_kernel(const uint32_t *cnt, uint32_t n, const uint32_t *bsum, uint32_t
     }
     uint32_t tp, ti;
     block256_exclusive_scan2(ap, ai, tp, ti, lds8);
-    uint32_t rp = bsum[blockIdx.x] + ap, ri = bsum[nb + blockIdx.x] + ai;
+    uint32_t carry_p, carry_i;
+    if (bsum) {
+        carry_p = bsum[blockIdx.x];
+        carry_i = bsum[nb + blockIdx.x];
+    } else {
+        // bsum == null (a level of few chunks): the block sums the chunks before its own itself, which costs less than
+        // the two launches that would hand it the sums; the last block also writes the totals
+        __shared__ uint32_t red[8];
+        const uint32_t lim = blockIdx.x * kPairScanChunk;
+        uint32_t sp = 0, si = 0;
+        for (uint32_t i0 = threadIdx.x; i0 < lim; i0 += 256 * 4) {
+            uint32_t c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = cnt[min(i0 + 256 * u, lim - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + 256 * u < lim) {
+                    sp += c[u];
+                    si += pair_items_of(c[u]);
+                }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sp += __shfl_xor(sp, o, 64);
+            si += __shfl_xor(si, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            red[threadIdx.x >> 6] = sp;
+            red[4 + (threadIdx.x >> 6)] = si;
+        }
+        __syncthreads();
+        carry_p = red[0] + red[1] + red[2] + red[3];
+        carry_i = red[4] + red[5] + red[6] + red[7];
+        if (blockIdx.x == nb - 1 && threadIdx.x == 0) {
+            poff[n] = carry_p + tp;
+            ioff[n] = carry_i + ti;
+        }
+    }
+    uint32_t rp = carry_p + ap, ri = carry_i + ai;
     for (uint32_t k = 0; k < 4; ++k) {
         const uint32_t i = base + k;
         if (i >= n) break;
