@@ -985,8 +985,9 @@ static void half_feedback_post(cuddle_index *ix, uint32_t nq, hipStream_t s) {
 // and wider than probes goes through the MFMA contraction + exact refinement; every other level
 // through the exact kernels. Both give the same selection.
 // feedback: the call may enqueue a copy and an event for HalfFeedback (not for callers that must enqueue kernels only).
+// zero_stats: the first kernel also clears the handle's device counters (the caller then needs no memset for them).
 static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, uint32_t flags,
-                                  hipStream_t s, bool feedback = true) {
+                                  hipStream_t s, bool feedback = true, bool zero_stats = false) {
     const IndexDev &v = ix->dev;
     const uint32_t stats = (flags & CUDDLE_SEARCH_STATS_VARIANT) ? 1u : 0u;
     half_feedback_poll(ix);
@@ -1000,7 +1001,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
     bool shared = !stats;
     launch_query_norms(ix, pl, dq, nq, s);
     hipLaunchKernelGGL(route_init_kernel, dim3((v.n_roots + 255) / 256, nq), dim3(256), 0, s, v.roots, v.n_roots,
-                       pl.frontier[0], pl.fstride, pl.fcount[0], pl.lcount, nq, shared ? 0u : 1u);
+                       pl.frontier[0], pl.fstride, pl.fcount[0], pl.lcount, nq, shared ? 0u : 1u,
+                       zero_stats ? reinterpret_cast<uint32_t *>(ix->d_stats) : nullptr, (uint32_t)(sizeof(DevStats) / 4));
     int cur = 0;
     uint64_t fb = v.n_roots;
     bool grouped = false; // this level's distances come from the (query, parent) pairs of the level above
@@ -1283,8 +1285,10 @@ static cuddle_status search_device_locked(cuddle_index *ix, const float *dq, uin
     if (!fixed_ws) ix->shard_state = 0; // the work space is about to be re-planned: an unfinished sharded batch is void
     ST_TRY(enter_stream(ix, s));
     ix->last_levels = ix->n_levels;
-    HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
-    if (nq == 0) return CUDDLE_OK;
+    if (nq == 0) {
+        HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
+        return CUDDLE_OK;
+    }
     Plan pl;
     ST_TRY(make_plan(ix, nq, k, probes, rerank_k, 0, pl, fixed_ws, fixed_cap));
     if (ix->timed) ix->timed_searches++;
@@ -1294,7 +1298,7 @@ static cuddle_status search_device_locked(cuddle_index *ix, const float *dq, uin
         mark(ix, s, CUDDLE_STAGE_QUANTIZE);
         ST_TRY(launch_quantize(ix, pl, q, qc, s));
         mark(ix, s, CUDDLE_STAGE_ROUTE);
-        ST_TRY(launch_route(ix, pl, q, qc, flags, s, fixed_ws == nullptr));
+        ST_TRY(launch_route(ix, pl, q, qc, flags, s, fixed_ws == nullptr, q0 == 0)); // (the first chunk's routing clears the counters)
         mark(ix, s, CUDDLE_STAGE_SCAN);
         ST_TRY(launch_scan_select(ix, pl, qc, s));
         mark(ix, s, CUDDLE_STAGE_RERANK);

@@ -337,10 +337,14 @@ route_materialise_kernel(IndexDev ix, const uint32_t *seg, uint32_t pstride, con
 
 // Level start: frontier = root_ids for every query (hierarchical.rs:346). write_roots = 0 when the
 // first level is evaluated from the shared root list.
+// zero != null: the first block also clears zero[0..n_zero) (a search's counters, instead of a memset launch of its own).
 __global__ void route_init_kernel(const uint32_t *roots, uint32_t n_roots, uint32_t *frontier, uint32_t fstride,
-                                  uint32_t *fcount, uint32_t *lcount, uint32_t nq, uint32_t write_roots) {
+                                  uint32_t *fcount, uint32_t *lcount, uint32_t nq, uint32_t write_roots,
+                                  uint32_t *zero = nullptr, uint32_t n_zero = 0) {
     uint32_t q = blockIdx.y;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero && q == 0 && blockIdx.x == 0)
+        for (uint32_t z = threadIdx.x; z < n_zero; z += blockDim.x) zero[z] = 0;
     if (q >= nq) return;
     if (write_roots && i < n_roots) frontier[(uint64_t)q * fstride + i] = roots[i];
     if (i == 0) {
