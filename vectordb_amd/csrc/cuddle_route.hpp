@@ -1072,6 +1072,50 @@ center_queries16_kernel(const float *queries, const float *mu, uint32_t nq, uint
     _Float16 *row = out + (uint64_t)q * kp;
     float s = 0.f, m = 0.f;
     const bool vec = (dim & 3) == 0 && (kp & 7) == 0;
+    if (vec && kp <= 1024) {
+        // rows of up to 1024 values: the lane's (at most four) 16-byte pieces of q and mu are all requested at once and
+        // stay in registers for both passes - one trip to memory instead of one per piece and pass
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        float4 x[4], u[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t i = min(4 * lane + 256 * c, dim - 4);
+            x[c] = *reinterpret_cast<const float4 *>(src + i);
+            u[c] = *reinterpret_cast<const float4 *>(mu + i);
+        }
+        float v[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool in = 4 * lane + 256 * c < dim;
+            v[c][0] = in ? x[c].x - u[c].x : 0.f; v[c][1] = in ? x[c].y - u[c].y : 0.f;
+            v[c][2] = in ? x[c].z - u[c].z : 0.f; v[c][3] = in ? x[c].w - u[c].w : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s = __builtin_fmaf(v[c][e], v[c][e], s);
+                m = fmaxf(m, fabsf(v[c][e]));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            m = fmaxf(m, __shfl_xor(m, o, 64));
+        }
+        const int se = half_scale_exp(m);
+        const float sc = ldexpf(1.0f, se);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t i = 4 * lane + 256 * c;
+            if (i < kp) {
+                f16x4 o = {(_Float16)(v[c][0] * sc), (_Float16)(v[c][1] * sc), (_Float16)(v[c][2] * sc), (_Float16)(v[c][3] * sc)};
+                *reinterpret_cast<f16x4 *>(row + i) = o;
+            }
+        }
+        if (lane == 0) {
+            sqn[q] = s;
+            inv[q] = ldexpf(1.0f, -se);
+        }
+        return;
+    }
     if (vec) {
         for (uint32_t i = 4 * lane; i < dim; i += 256) {
             const float4 x = *reinterpret_cast<const float4 *>(src + i), u = *reinterpret_cast<const float4 *>(mu + i);
