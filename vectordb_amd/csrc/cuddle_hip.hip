@@ -220,6 +220,11 @@ struct cuddle_index {
     bool half_pending = false;
     uint64_t half_q_total = 0, half_q_posted = 0, half_q_seen = 0; // queries routed through a half-filtered level
     uint32_t half_calls = 0;
+    // The per-query counts of a single-chunk search stay in the work space until the handle's next call; their sums
+    // (leaves, candidates, selections) are formed when cuddle_stats asks, not by a kernel behind every search.
+    const uint32_t *lazy_lcount = nullptr, *lazy_cand = nullptr, *lazy_sel = nullptr;
+    uint32_t lazy_nq = 0;
+    bool lazy_pending = false;
     uint32_t last_levels = 0;
     // leaf-sharded exact search: the plan of the batch between cuddle_shard_scan and cuddle_shard_finish
     Plan shard_plan;
@@ -851,6 +856,7 @@ static cuddle_status rerank_k_of(uint32_t k, uint32_t rf, uint32_t flags, uint64
 // A handle has ONE work space: a call on another stream than the previous call's first waits (on the host)
 // for that stream, so that it cannot overwrite the work space of a batch that is still running.
 static cuddle_status enter_stream(cuddle_index *ix, hipStream_t s) {
+    ix->lazy_pending = false; // the call about to run re-plans the work space (and clears the counters anyway)
     if (ix->stream_used && ix->last_stream != s) HIP_TRY(hipStreamSynchronize(ix->last_stream));
     ix->last_stream = s;
     ix->stream_used = true;
@@ -1246,8 +1252,10 @@ static cuddle_status launch_rerank(cuddle_index *ix, const Plan &pl, const float
     return CUDDLE_OK;
 }
 
+// lazy_stats: the per-query counts are summed when the statistics are read (single-chunk searches on the handle's own
+// work space) instead of by a launch here.
 static cuddle_status launch_topk(cuddle_index *ix, const Plan &pl, uint32_t nq, uint64_t *d_ids, float *d_dist,
-                                 uint32_t *d_count, hipStream_t s, uint64_t *d_order = nullptr) {
+                                 uint32_t *d_count, hipStream_t s, uint64_t *d_order = nullptr, bool lazy_stats = false) {
     const IndexDev &v = ix->dev;
     const uint32_t rk = v.code_kind == CUDDLE_CODE_RABITQ ? 1u : 0u;
 #define CUDDLE_TOPK_WAVE(KPL)                                                                                                 \
@@ -1264,8 +1272,14 @@ static cuddle_status launch_topk(cuddle_index *ix, const Plan &pl, uint32_t nq, 
         hipLaunchKernelGGL(topk_kernel, dim3(nq), dim3(256), lds, s, v, pl.sel_pos, pl.sel_key, pl.sel_dist, pl.sstride,
                            pl.sel_count, pl.k, rk, d_ids, d_dist, d_count, d_order ? pl.sel_ord : nullptr, d_order);
     }
-    hipLaunchKernelGGL(stats_accum_kernel, dim3(std::min<uint32_t>((nq + 255) / 256, 8)), dim3(256), 0, s, pl.lcount, pl.cand_count,
-                       pl.sel_count, nq, ix->d_stats);
+    if (lazy_stats) {
+        ix->lazy_lcount = pl.lcount; ix->lazy_cand = pl.cand_count; ix->lazy_sel = pl.sel_count;
+        ix->lazy_nq = nq;
+        ix->lazy_pending = true;
+    } else {
+        hipLaunchKernelGGL(stats_accum_kernel, dim3(std::min<uint32_t>((nq + 255) / 256, 8)), dim3(256), 0, s, pl.lcount, pl.cand_count,
+                           pl.sel_count, nq, ix->d_stats);
+    }
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
 }
@@ -1304,7 +1318,8 @@ static cuddle_status search_device_locked(cuddle_index *ix, const float *dq, uin
         mark(ix, s, CUDDLE_STAGE_RERANK);
         ST_TRY(launch_rerank(ix, pl, q, qc, s));
         mark(ix, s, CUDDLE_STAGE_TOPK);
-        ST_TRY(launch_topk(ix, pl, qc, d_ids + (uint64_t)q0 * k, d_dist + (uint64_t)q0 * k, d_count ? d_count + q0 : nullptr, s));
+        ST_TRY(launch_topk(ix, pl, qc, d_ids + (uint64_t)q0 * k, d_dist + (uint64_t)q0 * k, d_count ? d_count + q0 : nullptr, s,
+                           nullptr, !fixed_ws && nq <= pl.qc));
         mark(ix, s, -1);
     }
     return CUDDLE_OK;
@@ -1343,6 +1358,11 @@ extern "C" cuddle_status cuddle_search_batch_device_noalloc(cuddle_index *idx, c
 
 static cuddle_status read_stats(cuddle_index *ix, cuddle_stats *st) {
     DevStats h;
+    if (ix->lazy_pending) { // the last search left its per-query counts in the work space: sum them now
+        hipLaunchKernelGGL(stats_accum_kernel, dim3(std::min<uint32_t>((ix->lazy_nq + 255) / 256, 8)), dim3(256), 0, ix->last_stream,
+                           ix->lazy_lcount, ix->lazy_cand, ix->lazy_sel, ix->lazy_nq, ix->d_stats);
+        ix->lazy_pending = false;
+    }
     HIP_TRY(hipStreamSynchronize(ix->last_stream));
     HIP_TRY(hipMemcpy(&h, ix->d_stats, sizeof(h), hipMemcpyDeviceToHost));
     st->leaves_searched = h.leaves;
