@@ -883,12 +883,26 @@ static uint32_t host_next_pow2(uint32_t v) {
     return p;
 }
 
-static cuddle_status launch_quantize(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, hipStream_t s) {
+// route_init != null: the launch also sets up the routing state of the chunk (what route_init_kernel does; *route_init
+// tells launch_route that it has been done), clearing the handle's counters when zero_stats is set. Binary codes only:
+// *route_init stays false otherwise.
+static cuddle_status launch_quantize(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, hipStream_t s,
+                                     bool *route_init = nullptr, uint32_t flags = 0, bool zero_stats = false) {
     const IndexDev &v = ix->dev;
+    if (route_init) *route_init = false;
     if (v.code_kind == CUDDLE_CODE_BINARY) {
         uint64_t total = (uint64_t)nq * v.words;
+        const uint32_t qblocks = (uint32_t)((total + 3) / 4), rblocks = (v.n_roots + 255) / 256;
+        if (route_init && (uint64_t)qblocks + (uint64_t)rblocks * nq < (1u << 30)) {
+            hipLaunchKernelGGL(quantize_init_kernel, dim3(qblocks + rblocks * nq), dim3(256), 0, s, dq, (uint64_t)nq, v.dim, v.words,
+                               ix->threshold, pl.qcodes, qblocks, rblocks, v.roots, v.n_roots, pl.frontier[0], pl.fstride, pl.fcount[0],
+                               pl.lcount, nq, (flags & CUDDLE_SEARCH_STATS_VARIANT) ? 1u : 0u,
+                               zero_stats ? reinterpret_cast<uint32_t *>(ix->d_stats) : nullptr, (uint32_t)(sizeof(DevStats) / 4));
+            *route_init = true;
+        } else {
         hipLaunchKernelGGL(binary_quantize_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, dq, (uint64_t)nq,
                            v.dim, v.words, ix->threshold, pl.qcodes);
+        }
     } else {
         float *rq = reinterpret_cast<float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
         hipLaunchKernelGGL(rabitq_query_prep_kernel, dim3((nq + kPrepQ - 1) / kPrepQ), dim3(std::min(1024u, (v.dim + 63) & ~63u)), kPrepQ * v.dim * sizeof(float),
@@ -992,8 +1006,9 @@ static void half_feedback_post(cuddle_index *ix, uint32_t nq, hipStream_t s) {
 // through the exact kernels. Both give the same selection.
 // feedback: the call may enqueue a copy and an event for HalfFeedback (not for callers that must enqueue kernels only).
 // zero_stats: the first kernel also clears the handle's device counters (the caller then needs no memset for them).
+// init_done: the routing state has been set up already (launch_quantize did it in its own launch).
 static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, uint32_t flags,
-                                  hipStream_t s, bool feedback = true, bool zero_stats = false) {
+                                  hipStream_t s, bool feedback = true, bool zero_stats = false, bool init_done = false) {
     const IndexDev &v = ix->dev;
     const uint32_t stats = (flags & CUDDLE_SEARCH_STATS_VARIANT) ? 1u : 0u;
     half_feedback_poll(ix);
@@ -1006,6 +1021,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
     // search_with_stats re-orders every level).
     bool shared = !stats;
     launch_query_norms(ix, pl, dq, nq, s);
+    if (!init_done)
     hipLaunchKernelGGL(route_init_kernel, dim3((v.n_roots + 255) / 256, nq), dim3(256), 0, s, v.roots, v.n_roots,
                        pl.frontier[0], pl.fstride, pl.fcount[0], pl.lcount, nq, shared ? 0u : 1u,
                        zero_stats ? reinterpret_cast<uint32_t *>(ix->d_stats) : nullptr, (uint32_t)(sizeof(DevStats) / 4));
@@ -1310,9 +1326,10 @@ static cuddle_status search_device_locked(cuddle_index *ix, const float *dq, uin
         const uint32_t qc = std::min(pl.qc, nq - q0);
         const float *q = dq + (uint64_t)q0 * dim;
         mark(ix, s, CUDDLE_STAGE_QUANTIZE);
-        ST_TRY(launch_quantize(ix, pl, q, qc, s));
+        bool init_done = false;
+        ST_TRY(launch_quantize(ix, pl, q, qc, s, &init_done, flags, q0 == 0)); // (the first chunk's first launch clears the counters)
         mark(ix, s, CUDDLE_STAGE_ROUTE);
-        ST_TRY(launch_route(ix, pl, q, qc, flags, s, fixed_ws == nullptr, q0 == 0)); // (the first chunk's routing clears the counters)
+        ST_TRY(launch_route(ix, pl, q, qc, flags, s, fixed_ws == nullptr, q0 == 0 && !init_done, init_done));
         mark(ix, s, CUDDLE_STAGE_SCAN);
         ST_TRY(launch_scan_select(ix, pl, qc, s));
         mark(ix, s, CUDDLE_STAGE_RERANK);

@@ -700,17 +700,23 @@ __global__ void distance_pairs_kernel(const float *a, const float *b, uint64_t n
     if (act && sub == 0) out[g] = d;
 }
 
-// BinaryQuantizer::quantize (binary.rs:144-159): one wave per (vector, word); lane i tests value
-// 64 w + i (strict >), the wave's ballot is the word (bit i = lane i, pad bits 0).
-// grid = ceil(n * words / 4), block 256.
-__global__ void __launch_bounds__(256)
-binary_quantize_kernel(const float *v, uint64_t n, uint32_t dim, uint32_t words, float thr, uint64_t *codes) {
-    const uint64_t t = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+// The work of block `bid` of binary_quantize_kernel (256 threads: one wave per (vector, word)).
+__device__ __forceinline__ void binary_quantize_block(uint32_t bid, const float *v, uint64_t n, uint32_t dim, uint32_t words,
+                                                      float thr, uint64_t *codes) {
+    const uint64_t t = (uint64_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t >= n * words) return;
     const uint32_t lane = threadIdx.x & 63, w = (uint32_t)(t % words), i = w * 64 + lane;
     const bool bit = i < dim && v[(t / words) * dim + i] > thr;
     const uint64_t bits = __ballot(bit);
     if (lane == 0) codes[t] = bits;
+}
+
+// BinaryQuantizer::quantize (binary.rs:144-159): one wave per (vector, word); lane i tests value
+// 64 w + i (strict >), the wave's ballot is the word (bit i = lane i, pad bits 0).
+// grid = ceil(n * words / 4), block 256.
+__global__ void __launch_bounds__(256)
+binary_quantize_kernel(const float *v, uint64_t n, uint32_t dim, uint32_t words, float thr, uint64_t *codes) {
+    binary_quantize_block(blockIdx.x, v, n, dim, words, thr, codes);
 }
 
 // hamming_distance (binary.rs:42-54) for n pairs.

@@ -338,12 +338,11 @@ route_materialise_kernel(IndexDev ix, const uint32_t *seg, uint32_t pstride, con
 // Level start: frontier = root_ids for every query (hierarchical.rs:346). write_roots = 0 when the
 // first level is evaluated from the shared root list.
 // zero != null: the first block also clears zero[0..n_zero) (a search's counters, instead of a memset launch of its own).
-__global__ void route_init_kernel(const uint32_t *roots, uint32_t n_roots, uint32_t *frontier, uint32_t fstride,
-                                  uint32_t *fcount, uint32_t *lcount, uint32_t nq, uint32_t write_roots,
-                                  uint32_t *zero = nullptr, uint32_t n_zero = 0) {
-    uint32_t q = blockIdx.y;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (zero && q == 0 && blockIdx.x == 0)
+__device__ __forceinline__ void route_init_block(uint32_t bx, uint32_t q, const uint32_t *roots, uint32_t n_roots,
+                                                 uint32_t *frontier, uint32_t fstride, uint32_t *fcount, uint32_t *lcount,
+                                                 uint32_t nq, uint32_t write_roots, uint32_t *zero, uint32_t n_zero) {
+    uint32_t i = bx * blockDim.x + threadIdx.x;
+    if (zero && q == 0 && bx == 0)
         for (uint32_t z = threadIdx.x; z < n_zero; z += blockDim.x) zero[z] = 0;
     if (q >= nq) return;
     if (write_roots && i < n_roots) frontier[(uint64_t)q * fstride + i] = roots[i];
@@ -351,6 +350,26 @@ __global__ void route_init_kernel(const uint32_t *roots, uint32_t n_roots, uint3
         fcount[q] = n_roots;
         lcount[q] = 0;
     }
+}
+
+__global__ void route_init_kernel(const uint32_t *roots, uint32_t n_roots, uint32_t *frontier, uint32_t fstride,
+                                  uint32_t *fcount, uint32_t *lcount, uint32_t nq, uint32_t write_roots,
+                                  uint32_t *zero = nullptr, uint32_t n_zero = 0) {
+    route_init_block(blockIdx.x, blockIdx.y, roots, n_roots, frontier, fstride, fcount, lcount, nq, write_roots, zero, n_zero);
+}
+
+// A search's first two steps in one launch: blocks [0, qblocks) are binary_quantize_kernel's, the rest route_init_kernel's
+// (block qblocks + q * rblocks + bx does (bx, q)). Block 256.
+__global__ void __launch_bounds__(256)
+quantize_init_kernel(const float *v, uint64_t n, uint32_t dim, uint32_t words, float thr, uint64_t *codes, uint32_t qblocks,
+                     uint32_t rblocks, const uint32_t *roots, uint32_t n_roots, uint32_t *frontier, uint32_t fstride,
+                     uint32_t *fcount, uint32_t *lcount, uint32_t nq, uint32_t write_roots, uint32_t *zero, uint32_t n_zero) {
+    if (blockIdx.x < qblocks) {
+        binary_quantize_block(blockIdx.x, v, n, dim, words, thr, codes);
+        return;
+    }
+    const uint32_t r = blockIdx.x - qblocks;
+    route_init_block(r % rblocks, r / rblocks, roots, n_roots, frontier, fstride, fcount, lcount, nq, write_roots, zero, n_zero);
 }
 
 // ---------------------------------------------------------------------------------------------
