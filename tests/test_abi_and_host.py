@@ -130,3 +130,35 @@ def test_leaf_shards_partition_the_index_and_merge_back():
         _ffi.check(_ffi.lib().cuddle_merge_topk(_ffi.ptr(ids), _ffi.ptr(dist), world, 1, k, _ffi.ptr(oi), _ffi.ptr(od), None))
         assert np.array_equal(od[0], ref["dist"])
         assert sorted(oi[0].tolist()) == sorted(ref["ids"].tolist())
+
+
+def test_two_hip_runtimes_are_named_not_left_to_fail_later():
+    """Loading the library before torch leaves two libamdhip64 copies mapped (torch loads its own by file name);
+    the library then refuses to create an index and names both files, instead of torch reporting "no ROCm-capable
+    device" much later. Runs in a child process: the load order of this one is already decided."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, sys
+sys.path.insert(0, %r)
+lib = ctypes.CDLL(%r)            # the library first: bound to the system runtime
+import torch                      # torch maps its own copy
+import numpy as np
+from vectordb_amd import _ffi
+from vectordb_amd.flat_index import FlatIndex, pack_binary_codes
+x = np.zeros((4, 8), np.float32)
+fi = FlatIndex(dim=8, metric=0, code_kind=0, centroids=x[:1].copy(), child_offsets=np.zeros(2, np.uint32),
+               children=np.zeros(0, np.uint32), roots=np.zeros(1, np.uint32), vec_offsets=np.array([0, 4], np.uint64),
+               ids=np.arange(4, dtype=np.uint64), vectors=x, threshold=0.0, codes=pack_binary_codes(x, 0.0)).normalised()
+h = ctypes.c_void_p(None)
+d = fi.desc()
+st = _ffi.lib().cuddle_index_create(ctypes.byref(d), 0, ctypes.byref(h))
+print(st, _ffi.lib().cuddle_last_error().decode())
+''' % (str(ROOT), str(_ffi.LIB_PATH))
+    maps_has_two = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert maps_has_two.returncode == 0, maps_has_two.stderr[-2000:]
+    status, _, msg = maps_has_two.stdout.strip().partition(" ")
+    if "two HIP runtimes" not in msg:  # a torch build that uses the system runtime: nothing to detect
+        pytest.skip("torch shares the system HIP runtime here: " + msg[:200])
+    assert int(status) == _ffi.ERR_HIP
+    assert msg.count("libamdhip64") >= 2 and "torch" in msg

@@ -106,3 +106,25 @@ def test_recall_diagnostic_breakdown(gpu):
         assert m.true_nns_in_final_results <= m.true_nns_in_rerank_candidates <= m.true_nns_in_probed_leaves <= 10
     tight = summarise(diagnose(ci, q, gt, 10, 4, 1), 10)
     assert tight["final_recall"] <= tight["rerank_coverage_upper_bound"] <= tight["probe_coverage"]
+
+
+def test_last_stats_survive_a_growing_reserve(gpu):
+    """The sums behind cuddle_last_stats are formed lazily from per-query counts that stay in the handle's work
+    space; cuddle_index_reserve may replace that work space with a larger one in between. The statistics read after
+    the reserve must be those read straight after an identical search."""
+    import torch
+    x, fi = small_index(n=6000, d=48, n_clusters=40, branching=8, leaf=40, metric="l2")
+    q = torch.from_numpy(queries_like(x, 64, 5)).cuda(gpu)
+    dev = DeviceIndex(fi, gpu)
+    dev.search_batch_device(q, 10, 4, 5)
+    want = dev.last_stats()
+    assert want["vectors_scanned"] > 0 and want["leaves_searched"] > 0
+    dev.search_batch_device(q, 10, 4, 5)
+    before = dev.device_bytes
+    dev.reserve(4096, 100, 64, 10000)  # far larger than the 64-query search planned
+    assert dev.device_bytes > before
+    junk = torch.full((before // 4,), 0x7F7F7F7F, dtype=torch.int32, device=q.device)  # likely to land on the freed block
+    torch.cuda.synchronize()
+    got = dev.last_stats()
+    del junk
+    assert got == want

@@ -1,6 +1,7 @@
 """GPU: cuddle_search_batch_device_noalloc (work space in the library's fixed per-GPU array, no
 allocation) must give cuddle_search_batch_device's results bit for bit — on two calls in a row,
-the second with a smaller input, and for both code families."""
+the second with a smaller input, and for both code families; and that it allocates nothing: unchanged device memory on a
+handle that never ran the allocating call, two streams in turn, and a run under stream capture."""
 import ctypes as C
 
 import numpy as np
@@ -77,3 +78,59 @@ def test_noalloc_chunks_what_does_not_fit_at_once(gpu):
                                                 C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()),
                                                 C.c_void_p(out[2].data_ptr()), None)
     assert st == _ffi.ERR_BAD_DIM
+
+
+def test_noalloc_really_allocates_nothing(gpu):
+    """A fresh handle that has never run the allocating entry point: the no-allocation call must leave the handle's
+    device bytes and the GPU's free memory as they were, and must run inside a stream capture in global mode, where
+    any hipMalloc / hipFree / host wait fails the capture. The captured graph, replayed, gives the same results."""
+    x, fi = small_index(n=12000, d=64, n_clusters=60, branching=10, leaf=40, metric="l2", code_kind="binary")
+    dq = torch.from_numpy(queries_like(x, 300, 3)).cuda(gpu)
+    ref_dev = DeviceIndex(fi, gpu)
+    ref = [t.clone() for t in ref_dev.search_batch_device(dq, 10, 8, 20)]
+    torch.cuda.synchronize()
+    ref_dev.close()
+
+    dev = DeviceIndex(fi, gpu)  # never sees search_batch_device: its work space stays unallocated
+    out = (torch.full((300, 10), 7, dtype=torch.int64, device=dq.device), torch.full((300, 10), -1.0, device=dq.device),
+           torch.full((300,), 99, dtype=torch.int32, device=dq.device))
+    torch.cuda.synchronize()
+    bytes_before = dev.device_bytes
+    free_before = torch.cuda.mem_get_info(gpu)[0]
+    dev.search_batch_device_noalloc(dq, 10, 8, 20, 0, *out)
+    torch.cuda.synchronize()
+    assert dev.device_bytes == bytes_before
+    assert torch.cuda.mem_get_info(gpu)[0] == free_before
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[2], ref[2]) and np.array_equal(_bits(out[1]), _bits(ref[1]))
+
+    # two streams in turn: the second call is ordered behind the first on the device
+    s1, s2 = torch.cuda.Stream(gpu), torch.cuda.Stream(gpu)
+    out2 = tuple(torch.zeros_like(t) for t in out)
+    s1.wait_stream(torch.cuda.current_stream(gpu))
+    s2.wait_stream(torch.cuda.current_stream(gpu))
+    dev.search_batch_device_noalloc(dq, 10, 8, 20, 0, *out, stream=s1.cuda_stream)
+    dev.search_batch_device_noalloc(dq[:100].contiguous(), 10, 8, 20, 0, out2[0][:100], out2[1][:100], out2[2][:100],
+                                    stream=s2.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], ref[0]) and np.array_equal(_bits(out[1]), _bits(ref[1]))
+    assert torch.equal(out2[0][:100], ref[0][:100]) and np.array_equal(_bits(out2[1][:100]), _bits(ref[1][:100]))
+
+    # under capture: an allocation, a free or a host-side wait inside the call would end the capture with an error
+    for t in out:
+        t.fill_(0)
+    g = torch.cuda.CUDAGraph()
+    cs = torch.cuda.Stream(gpu)
+    cs.wait_stream(torch.cuda.current_stream(gpu))
+    with torch.cuda.graph(g, stream=cs, capture_error_mode="global"):
+        dev.search_batch_device_noalloc(dq, 10, 8, 20, 0, *out, stream=torch.cuda.current_stream(gpu).cuda_stream)
+    torch.cuda.synchronize()
+    assert int(out[2].sum()) == 0  # captured, not run
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[2], ref[2]) and np.array_equal(_bits(out[1]), _bits(ref[1]))
+    for t in out:
+        t.fill_(0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], ref[0]) and np.array_equal(_bits(out[1]), _bits(ref[1]))
+    assert dev.device_bytes == bytes_before

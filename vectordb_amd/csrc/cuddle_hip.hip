@@ -5,11 +5,15 @@
 // every compute entry point returns CUDDLE_ERR_NO_DEVICE.
 #include "../../include/cuddle_hip.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <climits>
+#include <cstdlib>
 #include <limits>
 #include <mutex>
 #include <string>
@@ -52,6 +56,35 @@ static cuddle_status fail(cuddle_status st, const char *fmt, ...) {
         if (s__ != CUDDLE_OK) return s__;   \
     } while (0)
 
+// Two HIP runtimes in one process. PyTorch wheels carry their own libamdhip64 and load it by file name; this library
+// is linked against the system's. When this library is loaded first, both end up mapped, each with its own view of
+// the devices, and the second one to start reports "no ROCm-capable device" - far from the cause. The library
+// therefore refuses to create an index in such a process and names both files (CUDDLE_ALLOW_TWO_HIP_RUNTIMES=1
+// overrides, for hosts that never touch the GPU through the other copy).
+static cuddle_status check_hip_runtime() {
+    if (getenv("CUDDLE_ALLOW_TWO_HIP_RUNTIMES")) return CUDDLE_OK;
+    Dl_info info{};
+    char mine[PATH_MAX] = "", other[PATH_MAX], line[PATH_MAX + 128];
+    if (!dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) || !info.dli_fname || !realpath(info.dli_fname, mine))
+        return CUDDLE_OK; // cannot tell which runtime this library is bound to
+    FILE *f = fopen("/proc/self/maps", "r");
+    if (!f) return CUDDLE_OK;
+    cuddle_status st = CUDDLE_OK;
+    while (st == CUDDLE_OK && fgets(line, sizeof(line), f)) {
+        const char *path = strchr(line, '/');
+        if (!path || !strstr(path, "/libamdhip64.so")) continue;
+        std::string p(path);
+        while (!p.empty() && (p.back() == '\n' || p.back() == ' ')) p.pop_back();
+        if (!realpath(p.c_str(), other) || strcmp(other, mine) == 0) continue;
+        st = fail(CUDDLE_ERR_HIP,
+                  "two HIP runtimes are loaded in this process: libcuddle_hip.so is bound to %s, and %s is mapped as well. "
+                  "Load the other user of HIP first (Python: `import torch` before vectordb_amd), so that one runtime serves both",
+                  mine, other);
+    }
+    fclose(f);
+    return st;
+}
+
 static cuddle_status use_device(int device_id) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -76,6 +109,8 @@ static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 static constexpr int kMaxDevices = 64;
 static std::mutex g_scratch_mu;
 static void *g_scratch_ptr[kMaxDevices];          // device address of `scratch` on each device, once resolved
+static hipEvent_t g_scratch_ev[kMaxDevices];      // orders a call behind the previous user's stream (created with the address)
+static std::mutex g_scratch_call_mu[kMaxDevices]; // held across a whole enqueue that uses the device's array
 static hipStream_t g_scratch_stream[kMaxDevices]; // stream of the last call that used it
 static bool g_scratch_used[kMaxDevices];
 
@@ -90,10 +125,34 @@ static cuddle_status scratch_for_device(int device_id, void **out) {
             (void)hipGetLastError();
             return fail(CUDDLE_ERR_HIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", device_id, hipGetErrorString(e));
         }
+        e = hipEventCreateWithFlags(&g_scratch_ev[device_id], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(CUDDLE_ERR_HIP, "hipEventCreate failed on device %d: %s", device_id, hipGetErrorString(e));
+        }
         g_scratch_ptr[device_id] = p;
     }
     *out = g_scratch_ptr[device_id];
     return CUDDLE_OK;
+}
+
+// Is `s` recording a graph? Calls that would wait, record events for later calls or copy to the host are left out then.
+static bool stream_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
+// Orders stream `s` behind everything enqueued so far on `prev`, on the device: no host wait. If `prev` no longer
+// exists (its owner destroyed it) the whole device is waited for instead, once, and the call goes on.
+static void order_after(hipStream_t prev, hipStream_t s, hipEvent_t ev) {
+    if (ev && hipEventRecord(ev, prev) == hipSuccess && hipStreamWaitEvent(s, ev, 0) == hipSuccess) return;
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -210,6 +269,7 @@ struct cuddle_index {
     uint32_t timed_searches = 0;
     hipStream_t last_stream = nullptr;
     bool stream_used = false; // last_stream names the stream of an earlier call
+    hipEvent_t ws_ev = nullptr; // orders a call on another stream behind the previous call's stream (enter_stream)
     // The single-pass half-precision routing filter is judged per level by how often its proof fails: a level whose
     // queries fall back to the exact kernels too often goes back to the split filter for good (HalfFeedback below).
     std::vector<uint8_t> half_ok;      // [n_levels] the level may use the half-precision filter
@@ -238,6 +298,7 @@ struct cuddle_index {
         if (d_half_fb) (void)hipFree(d_half_fb);
         if (h_half_fb) (void)hipHostFree(h_half_fb);
         if (half_ev) (void)hipEventDestroy(half_ev);
+        if (ws_ev) (void)hipEventDestroy(ws_ev);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
     }
 };
@@ -435,6 +496,7 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     std::vector<std::vector<uint32_t>> level_nodes;
     uint32_t n_levels = 0;
     ST_TRY(validate_desc(d, depth, n_levels, level_width, level_nodes));
+    ST_TRY(check_hip_runtime());
     ST_TRY(use_device(device_id));
     cuddle_index *ix = new (std::nothrow) cuddle_index();
     if (!ix) return fail(CUDDLE_ERR_OOM, "host allocation failed");
@@ -630,6 +692,7 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     HIP_TRY(hipHostMalloc((void **)&ix->h_half_fb, std::max<size_t>(ix->n_levels, 1) * 4, hipHostMallocDefault));
     memset(ix->h_half_fb, 0, std::max<size_t>(ix->n_levels, 1) * 4);
     HIP_TRY(hipEventCreateWithFlags(&ix->half_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ix->ws_ev, hipEventDisableTiming));
     ST_TRY(scratch_for_device(device_id, &ix->scratch_ptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipGetLastError());
@@ -757,6 +820,15 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     return off;
 }
 
+// Sums the per-query counts that the last single-chunk search left in the work space into the device counters
+// (on that search's stream), if that has not happened yet.
+static void flush_lazy_stats(cuddle_index *ix) {
+    if (!ix->lazy_pending) return;
+    hipLaunchKernelGGL(stats_accum_kernel, dim3(std::min<uint32_t>((ix->lazy_nq + 255) / 256, 8)), dim3(256), 0, ix->last_stream,
+                       ix->lazy_lcount, ix->lazy_cand, ix->lazy_sel, ix->lazy_nq, ix->d_stats);
+    ix->lazy_pending = false;
+}
+
 // lstride_min: lower bound for the leaf-list capacity (stage entry points pass their own lists).
 // fixed_base != null: the work space is that device buffer of fixed_cap bytes (nothing is allocated).
 // whole_index: the selection is made over this index alone, so a selection size beyond the candidates a query can
@@ -833,6 +905,9 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
                         pl.bytes, fixed_cap);
         carve_plan(ix, pl, static_cast<char *>(fixed_base));
     } else {
+        // growing the work space frees the old one: the per-query counts a search left there for cuddle_last_stats
+        // are summed first (a search re-plans after enter_stream() has dropped them; cuddle_index_reserve has not)
+        if (pl.bytes > ix->ws.bytes) flush_lazy_stats(ix);
         ST_TRY(ix->ws.ensure(pl.bytes));
         carve_plan(ix, pl, static_cast<char *>(ix->ws.p));
     }
@@ -853,11 +928,13 @@ static cuddle_status rerank_k_of(uint32_t k, uint32_t rf, uint32_t flags, uint64
 // ---------------------------------------------------------------------------------------------
 // stage launchers (device pointers, asynchronous on `s`)
 // ---------------------------------------------------------------------------------------------
-// A handle has ONE work space: a call on another stream than the previous call's first waits (on the host)
-// for that stream, so that it cannot overwrite the work space of a batch that is still running.
+// A handle has ONE work space: a call on another stream than the previous call's is ordered behind that stream
+// (an event recorded there now, awaited by `s`: no host wait), so that it cannot overwrite the work space of a batch
+// that is still running. A stream that is recording a graph is left alone: whoever replays the graph orders the replays.
 static cuddle_status enter_stream(cuddle_index *ix, hipStream_t s) {
     ix->lazy_pending = false; // the call about to run re-plans the work space (and clears the counters anyway)
-    if (ix->stream_used && ix->last_stream != s) HIP_TRY(hipStreamSynchronize(ix->last_stream));
+    if (stream_capturing(s)) return CUDDLE_OK;
+    if (ix->stream_used && ix->last_stream != s) order_after(ix->last_stream, s, ix->ws_ev);
     ix->last_stream = s;
     ix->stream_used = true;
     return CUDDLE_OK;
@@ -1011,7 +1088,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                                   hipStream_t s, bool feedback = true, bool zero_stats = false, bool init_done = false) {
     const IndexDev &v = ix->dev;
     const uint32_t stats = (flags & CUDDLE_SEARCH_STATS_VARIANT) ? 1u : 0u;
-    half_feedback_poll(ix);
+    if (feedback) half_feedback_poll(ix);
     bool used_half = false;
     auto half_on = [&](uint32_t l) { // the level's filter: single-pass half precision unless told or taught otherwise
         return ix->lvl[l].table16 && !(flags & CUDDLE_SEARCH_ROUTE_SPLIT_FILTER) && !no_half_env() && ix->half_ok[l];
@@ -1362,10 +1439,13 @@ extern "C" cuddle_status cuddle_search_batch_device_noalloc(cuddle_index *idx, c
     ST_TRY(use_device(idx->device));
     if (!idx->scratch_ptr) return fail(CUDDLE_ERR_HIP, "the fixed work space was not resolved on device %d", idx->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    { // the array is shared by every handle on this GPU: a call on another stream than the last one waits for that stream
-        std::lock_guard<std::mutex> lk2(g_scratch_mu);
-        const int d = idx->device;
-        if (g_scratch_used[d] && g_scratch_stream[d] != s) HIP_TRY(hipStreamSynchronize(g_scratch_stream[d]));
+    const int d = idx->device;
+    // The array is shared by every handle on this GPU: one enqueue at a time, and a call on another stream than the
+    // last one is ordered behind that stream on the device. (Under graph capture nothing is awaited or recorded.)
+    std::lock_guard<std::mutex> lk2(g_scratch_call_mu[d]);
+    const bool capturing = stream_capturing(s);
+    if (!capturing) {
+        if (g_scratch_used[d] && g_scratch_stream[d] != s) order_after(g_scratch_stream[d], s, g_scratch_ev[d]);
         g_scratch_stream[d] = s;
         g_scratch_used[d] = true;
     }
@@ -1375,12 +1455,11 @@ extern "C" cuddle_status cuddle_search_batch_device_noalloc(cuddle_index *idx, c
 
 static cuddle_status read_stats(cuddle_index *ix, cuddle_stats *st) {
     DevStats h;
-    if (ix->lazy_pending) { // the last search left its per-query counts in the work space: sum them now
-        hipLaunchKernelGGL(stats_accum_kernel, dim3(std::min<uint32_t>((ix->lazy_nq + 255) / 256, 8)), dim3(256), 0, ix->last_stream,
-                           ix->lazy_lcount, ix->lazy_cand, ix->lazy_sel, ix->lazy_nq, ix->d_stats);
-        ix->lazy_pending = false;
+    flush_lazy_stats(ix); // the last search left its per-query counts in the work space: sum them now
+    if (hipStreamSynchronize(ix->last_stream) != hipSuccess) { // the caller destroyed that stream: wait for the device
+        (void)hipGetLastError();
+        HIP_TRY(hipDeviceSynchronize());
     }
-    HIP_TRY(hipStreamSynchronize(ix->last_stream));
     HIP_TRY(hipMemcpy(&h, ix->d_stats, sizeof(h), hipMemcpyDeviceToHost));
     st->leaves_searched = h.leaves;
     st->vectors_scanned = h.scanned;
