@@ -215,6 +215,7 @@ struct Plan {
     uint32_t *thr = nullptr;
     uint64_t *sel_ord = nullptr;
     float *qnorm = nullptr; // cosine: sqrt(dot(q, q)) per query
+    uint32_t *rq_rows = nullptr; // RaBitQ: [qc][rq_plane_stride] quantised query magnitudes as bit planes (rabitq_query_planes_kernel)
     uint32_t *level_fc = nullptr; // [n_levels + 1][qc] frontier size of every query at every level (stats variant)
     uint32_t *leaf_tables = nullptr; // [qc][4][lstride + 4] per-slot tables of the reached leaves (cand_count_kernel)
     uint32_t *sel_pos = nullptr, *sel_key = nullptr, *sel_count = nullptr, *cand_count = nullptr;
@@ -654,7 +655,7 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
         }
         v.codes = reinterpret_cast<const uint4 *>(planar);
     } else {
-        float *rot, *rot_tr = nullptr, *norm, *ipoo; uint32_t *rc = nullptr, *raw = nullptr;
+        float *rot, *rot_tr = nullptr, *norm, *ipoo; uint32_t *rc = nullptr, *raw = nullptr, *rvm = nullptr;
         st = upload(ix, d->rabitq_rot_t, (size_t)D * D, &rot);
         if (st == CUDDLE_OK) st = dev_alloc(ix, (size_t)D * D, &rot_tr);
         if (st == CUDDLE_OK)
@@ -676,10 +677,20 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
             if (st == CUDDLE_OK)
                 hipLaunchKernelGGL(relayout_rabitq_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, src, rc,
                                    vec_off, d_pos_leaf, N, W32);
+            // the same codes once more, vector-major (rows of whole 16-byte pieces): the exact estimates of the few
+            // candidates the bounds leave undecided read one vector's code as one contiguous piece
+            const uint32_t vmw = (W32 + 3) & ~3u;
+            if (st == CUDDLE_OK) st = dev_alloc(ix, (size_t)N * vmw, &rvm);
+            if (st == CUDDLE_OK) {
+                const uint64_t total = N * (uint64_t)vmw, per = (1ull << 23) * 256;
+                for (uint64_t t0 = 0; t0 < total; t0 += per)
+                    hipLaunchKernelGGL(pad_rabitq_rows_kernel, dim3((unsigned)((std::min(per, total - t0) + 255) / 256)), dim3(256), 0, 0,
+                                       src, rvm, N, W32, vmw, t0);
+            }
             (void)hipDeviceSynchronize();
             if (raw) (void)hipFree(raw);
         }
-        if (st == CUDDLE_OK) { v.rot_t = rot; v.rot = rot_tr; v.rq_norm = norm; v.rq_ipoo = ipoo; v.rq_codes = rc; }
+        if (st == CUDDLE_OK) { v.rot_t = rot; v.rot = rot_tr; v.rq_norm = norm; v.rq_ipoo = ipoo; v.rq_codes = rc; v.rq_codes_vm = rvm; v.rq_vm_words = (W32 + 3) & ~3u; }
     }
     if (d_pos_leaf) (void)hipFree(d_pos_leaf);
     if (st != CUDDLE_OK) return st;
@@ -794,6 +805,7 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     size_t o_lfc = carve(qc * ((size_t)ix->n_levels + 1) * 4);
     size_t o_ltb = carve(qc * 4 * ((size_t)pl.lstride + 4) * 4);
     size_t o_sg0 = carve(qc * seg_stride(pl.probes) * 4), o_sg1 = carve(qc * seg_stride(pl.probes) * 4);
+    size_t o_rqr = carve(v.code_kind == CUDDLE_CODE_RABITQ ? qc * (size_t)rq_plane_stride(v.words32) * 4 : 0);
     if (!b) return off;
     pl.qcodes = (uint64_t *)(b + o_qcodes);
     pl.frontier[0] = (uint32_t *)(b + o_f0); pl.frontier[1] = (uint32_t *)(b + o_f1);
@@ -817,6 +829,7 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     pl.level_fc = (uint32_t *)(b + o_lfc);
     pl.leaf_tables = (uint32_t *)(b + o_ltb);
     pl.seg[0] = (uint32_t *)(b + o_sg0); pl.seg[1] = (uint32_t *)(b + o_sg1);
+    pl.rq_rows = (uint32_t *)(b + o_rqr);
     return off;
 }
 
@@ -984,6 +997,7 @@ static cuddle_status launch_quantize(cuddle_index *ix, const Plan &pl, const flo
         float *rq = reinterpret_cast<float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
         hipLaunchKernelGGL(rabitq_query_prep_kernel, dim3((nq + kPrepQ - 1) / kPrepQ), dim3(std::min(1024u, (v.dim + 63) & ~63u)), kPrepQ * v.dim * sizeof(float),
                            s, dq, v.rot, nq, v.dim, rq, qn);
+        hipLaunchKernelGGL(rabitq_query_planes_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, rq, qn, nq, v.dim, v.words32, pl.rq_rows);
     }
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
@@ -1323,7 +1337,7 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
         hipLaunchKernelGGL(scan_select_rabitq_kernel, dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, rq, qn, pl.leaf_tables,
                            tstride, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, reinterpret_cast<float *>(pl.gdist),
                            pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, rabitq_exact_all ? 1u : 0u,
-                           &ix->d_stats->rq_exact);
+                           &ix->d_stats->rq_exact, pl.rq_rows);
         hipLaunchKernelGGL(selection_sort_f32_kernel, dim3(nq), dim3(256), (size_t)host_next_pow2(pl.sstride) * 8, s,
                            pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.sel_ord);
         HIP_TRY(hipGetLastError());

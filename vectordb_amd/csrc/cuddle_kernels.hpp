@@ -43,6 +43,8 @@ struct IndexDev {
     const float *rq_norm;         // [n_vectors]
     const float *rq_ipoo;         // [n_vectors]
     uint32_t words32;             // ceil(dim/32)
+    uint32_t rq_vm_words;         // u32 per vector in rq_codes_vm: words32 rounded up to a multiple of 4
+    const uint32_t *rq_codes_vm;  // [n_vectors][rq_vm_words] the same codes vector-major, zero padded (16-byte aligned rows)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -792,6 +794,16 @@ __global__ void relayout_rabitq_kernel(const uint32_t *src, uint32_t *dst, const
     uint32_t n = vec_off[leaf + 1] - vec_off[leaf];
     uint32_t *base = dst + beg * words32;
     for (uint32_t w = 0; w < words32; ++w) base[(uint64_t)w * n + i] = src[p * words32 + w];
+}
+
+// Vector-major copy of the RaBitQ codes with rows padded to whole 16-byte pieces.
+__global__ void pad_rabitq_rows_kernel(const uint32_t *src, uint32_t *dst, uint64_t n_vectors, uint32_t words32, uint32_t vm_words,
+                                       uint64_t t0) {
+    const uint64_t t = t0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_vectors * vm_words) return;
+    const uint64_t p = t / vm_words;
+    const uint32_t w = (uint32_t)(t % vm_words);
+    dst[t] = w < words32 ? src[p * words32 + w] : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -145,12 +145,15 @@ __device__ __forceinline__ void rabitq_stage_query(const float *rq, uint32_t dim
 // plane); the error bound halves with every plane, and below ten the band of candidates that need the exact
 // estimate starts to cost more than the planes save (10M x 768-d, k 100, rerank factor 10: 12 planes 2.03 ms,
 // 11 1.96, 10 1.91, 9 1.90).
-constexpr uint32_t kRqPlanes = 10;
+#ifndef CUDDLE_RQ_PLANES
+#define CUDDLE_RQ_PLANES 10
+#endif
+constexpr uint32_t kRqPlanes = CUDDLE_RQ_PLANES;
 constexpr uint32_t kRqListCap = 4096; // candidates whose exact estimate is needed; more: every candidate is evaluated exactly
 
 inline size_t rabitq_scan_lds_bytes(uint32_t dim, uint32_t lcap, uint32_t tcap, uint32_t dist_cap) {
     return scan_lds_bytes(0, 0, lcap, tcap, 0) + 256 * 4 + (size_t)((dim + 3) & ~3u) * 4 + (size_t)((dim + 63) / 64) * 8 +
-           (size_t)kRqPlanes * 2 * ((dim + 63) / 64) * 4 + (size_t)kRqListCap * 4 + 32 * 4 + (size_t)dist_cap * 4 + 96;
+           (size_t)kRqListCap * 4 + 32 * 4 + (size_t)dist_cap * 4 + 96;
 }
 
 struct RabitqLds {
@@ -158,9 +161,8 @@ struct RabitqLds {
     uint32_t *rhist; // [256] radix-select histogram
     float *rq;       // [dim]  |rotated query|
     uint32_t *qsign; // [2 * ceil(dim / 64)] sign bits of the rotated query
-    uint32_t *planes; // [2 * ceil(dim / 64)][kRqPlanes] bit planes of the quantised magnitudes, the planes of a word together
     uint32_t *list;  // [kRqListCap] scan positions of the candidates to evaluate exactly
-    float *fsc;      // [16] per-query scalars of the bound; [16..31] the same memory seen as u32 counters
+    float *fsc;      // [16] unused; [16..31] the same memory seen as u32 counters
     float *est;      // [dist_cap]
 };
 
@@ -172,7 +174,6 @@ __device__ __forceinline__ RabitqLds rabitq_lds_carve(unsigned char *smem, uint3
     r.rhist = p; p += 256;
     r.rq = reinterpret_cast<float *>(p); p += (dim + 3) & ~3u;
     r.qsign = p; p += 2 * ((dim + 63) / 64);
-    r.planes = p; p += kRqPlanes * 2 * ((dim + 63) / 64);
     r.list = p; p += kRqListCap;
     r.fsc = reinterpret_cast<float *>(p); p += 32;
     p = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
@@ -240,41 +241,54 @@ __device__ __forceinline__ float rabitq_estimate_from_ip(float ip, float qnorm, 
     return dn * norm * qnorm;
 }
 
-// Quantises the staged magnitudes (r.rq) to kRqPlanes bits and leaves the per-query scalars of the bound in
-// r.fsc: [0] delta, [1] a_q, [2] b_q (E_c = norm_c * (a_q + b_q / ip_oo_c)), and in the u32 view [16] = sum of
-// the quantised values. All threads call (whole waves); barriers inside; the caller has synchronised after
-// rabitq_stage_query.
-__device__ __forceinline__ void rabitq_quantise_query(const RabitqLds &r, uint32_t dim, float qnorm) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+// The bound's query side lives in global memory, one row of rq_plane_stride(words32) u32 per query, written once
+// per batch by rabitq_query_planes_kernel and read by the scan through scalar loads (the row is the same for every
+// lane, so its words sit in scalar registers and cost the vector unit nothing):
+//   [0] delta (f32)  [1] a_q (f32)  [2] b_q (f32)   (E_c = norm_c * (a_q + b_q / ip_oo_c))   [3] sum of the quantised values
+//   [8 + 12 w + 0] sign bits of rq (dimensions 32 w .. 32 w + 31)   [8 + 12 w + 1 + p] bit plane p of the quantised magnitudes
+constexpr uint32_t kRqWordStride = (kRqPlanes + 1 + 3) & ~3u; // sign word + planes, padded to whole 16-byte pieces
+__host__ __device__ inline uint32_t rq_plane_stride(uint32_t words32) { return 8 + kRqWordStride * words32; }
+
+// Quantises |rq| of every query to kRqPlanes bits and writes its row (layout above). One wave per query.
+__global__ void __launch_bounds__(256)
+rabitq_query_planes_kernel(const float *rq_all, const float *qnorm_all, uint32_t nq, uint32_t dim, uint32_t words32,
+                           uint32_t *rows) {
+    const uint32_t lane = threadIdx.x & 63, q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float *rq = rq_all + (uint64_t)q * dim;
+    uint32_t *row = rows + (uint64_t)q * rq_plane_stride(words32);
+    const float qnorm = qnorm_all[q];
+    const bool live = qnorm >= 1e-10f; // rq is undefined for a zero query (the scan does not use the bounds then)
     const uint32_t dpad = (dim + 63) & ~63u;
-    uint32_t *isc = reinterpret_cast<uint32_t *>(r.fsc) + 16;
-    float *wsum = reinterpret_cast<float *>(r.rhist); // per-wave partial results (the histogram is free until the selection)
     float mx = 0.f;
-    for (uint32_t i = tid; i < dim; i += blockDim.x) mx = fmaxf(mx, r.rq[i]);
+    for (uint32_t i = lane; i < dim; i += 64) mx = fmaxf(mx, live ? fabsf(rq[i]) : 0.f);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if (lane == 0) wsum[w] = mx;
-    __syncthreads();
-    mx = 0.f;
-    for (uint32_t v = 0; v < nw; ++v) mx = fmaxf(mx, wsum[v]);
-    __syncthreads();
     constexpr uint32_t VMAX = (1u << kRqPlanes) - 1;
     const float delta = mx / (float)VMAX, inv = mx > 0.f ? (float)VMAX / mx : 0.f;
     float res = 0.f, asum = 0.f;
     uint32_t vsum = 0;
-    for (uint32_t i = tid; i < dpad; i += blockDim.x) {
-        const float a = i < dim ? r.rq[i] : 0.f;
+    for (uint32_t i = lane; i < dpad; i += 64) {
+        const uint32_t bits = (i < dim && live) ? __float_as_uint(rq[i]) : 0u;
+        const float a = __uint_as_float(bits & 0x7FFFFFFFu);
         uint32_t v = (uint32_t)rintf(a * inv);
         v = (a == a && v <= VMAX) ? v : (a == a ? VMAX : 0u);
         res += fabsf(a - delta * (float)v);
         asum += a;
         vsum += v;
+        const uint64_t sb = __ballot((bits >> 31) != 0);
+        uint32_t *w0 = row + 8 + (size_t)kRqWordStride * (i >> 5); // i is a multiple of 64 in lane 0
+        const bool second = (i >> 5) + 1 < words32;
+        if (lane == 0) {
+            w0[0] = (uint32_t)sb;
+            if (second) w0[kRqWordStride] = (uint32_t)(sb >> 32);
+        }
 #pragma unroll
         for (uint32_t p = 0; p < kRqPlanes; ++p) {
             const uint64_t bal = __ballot((v >> p) & 1u);
             if (lane == 0) {
-                r.planes[(i >> 5) * kRqPlanes + p] = (uint32_t)bal;
-                r.planes[((i >> 5) + 1) * kRqPlanes + p] = (uint32_t)(bal >> 32);
+                w0[1 + p] = (uint32_t)bal;
+                if (second) w0[kRqWordStride + 1 + p] = (uint32_t)(bal >> 32);
             }
         }
     }
@@ -285,72 +299,103 @@ __device__ __forceinline__ void rabitq_quantise_query(const RabitqLds &r, uint32
         vsum += __shfl_xor(vsum, o, 64);
     }
     if (lane == 0) {
-        wsum[w] = res;
-        wsum[16 + w] = asum;
-        reinterpret_cast<uint32_t *>(wsum)[32 + w] = vsum;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float R = 0.f, A = 0.f;
-        uint32_t V = 0;
-        for (uint32_t v = 0; v < nw; ++v) {
-            R += wsum[v];
-            A += wsum[16 + v];
-            V += reinterpret_cast<uint32_t *>(wsum)[32 + v];
-        }
         // |ip~ - ip| <= B: quantisation residue (computed in f32: 0.2 % slack) + the rounding of the reference's
         // sequential f32 sum and of delta * integer (each below dim * 2^-23 times the sum of magnitudes)
-        const float B = 1.002f * R + ((float)dim + 8.0f) * 1.2e-7f * (A + R);
+        const float B = 1.002f * res + ((float)dim + 8.0f) * 1.2e-7f * (asum + res);
         // E_c = norm_c qnorm (2 B / ip_oo + 1e-5 (1 + (A + B) / ip_oo)), 0.1 % slack: the second term covers the
         // roundings of (2 - 2 ip / ip_oo) norm qnorm in either evaluation and of the bound itself
-        r.fsc[0] = delta;
-        r.fsc[1] = 1.001f * qnorm * 1e-5f;
-        r.fsc[2] = 1.001f * qnorm * (2.0f * B + 1e-5f * (A + B));
-        isc[0] = V;
+        row[0] = __float_as_uint(delta);
+        row[1] = __float_as_uint(1.001f * qnorm * 1e-5f);
+        row[2] = __float_as_uint(1.001f * qnorm * (2.0f * B + 1e-5f * (asum + B)));
+        row[3] = vsum;
     }
-    __syncthreads();
+}
+
+// popcount(x) + acc in one instruction (the compiler otherwise splits it into a count and a three-way add).
+__device__ __forceinline__ void popc_acc(uint32_t &acc, uint32_t x) {
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x));
 }
 
 // Upper bound est~ + E (returned) and lower bound est~ - E (lb) of the estimate of vector i of a leaf (codes
-// word-major [w][n]); see the section comment. Both are rounded outwards.
-__device__ __forceinline__ float rabitq_bounds(const uint32_t *codes, uint32_t n, uint32_t i, uint32_t words32,
-                                               const RabitqLds &r, float qnorm, float norm, float ipoo, float &lb) {
+// word-major [w][n]); see the section comment. Both are rounded outwards. `codes`, `n` and `row` (the query's row
+// of rabitq_query_planes_kernel) are the same for every lane of the wave: the code words are loaded from a scalar
+// row base + the lane's own 4 i bytes, and the planes come through scalar loads.
+__device__ __forceinline__ float rabitq_bounds(const uint32_t *__restrict__ codes, uint32_t n, uint32_t i, uint32_t words32,
+                                               const uint32_t *__restrict__ row, float qnorm, float norm, float ipoo, float &lb) {
     if (norm < 1e-10f) { // exact (rabitq.rs:342-349)
         lb = qnorm * qnorm;
         return lb;
     }
-    const LdsU32 *ls = (const LdsU32 *)r.qsign;
-    const LdsU32 *pl = (const LdsU32 *)r.planes;
     uint32_t cnt[kRqPlanes];
 #pragma unroll
     for (uint32_t p = 0; p < kRqPlanes; ++p) cnt[p] = 0;
-    // straight-line chunks of 16, 8 and 1 code words (no condition between a load and its use, or the compiler
-    // sinks every load next to its use and waits for each in turn): the loop is bound by memory latency
+    // straight-line chunks of 8 and 1 code words (no condition between a load and its use, or the compiler sinks
+    // every load next to its use and waits for each in turn)
     auto chunk = [&](uint32_t w, auto ch) {
         constexpr uint32_t CH = decltype(ch)::value;
         uint32_t cw[CH];
 #pragma unroll
-        for (uint32_t u = 0; u < CH; ++u) cw[u] = codes[(uint64_t)(w + u) * n + i];
+        for (uint32_t u = 0; u < CH; ++u) cw[u] = (codes + (uint64_t)(w + u) * n)[i];
 #pragma unroll
         for (uint32_t u = 0; u < CH; ++u) {
-            const uint32_t d = ls[w + u] ^ ~cw[u]; // bit i set: term i is negative
+            const uint32_t *pw = row + 8 + kRqWordStride * (w + u);
+            const uint32_t d = pw[0] ^ ~cw[u]; // bit i set: term i is negative
 #pragma unroll
-            for (uint32_t p = 0; p < kRqPlanes; ++p) cnt[p] += __popc(d & pl[(w + u) * kRqPlanes + p]);
+            for (uint32_t p = 0; p < kRqPlanes; ++p) popc_acc(cnt[p], d & pw[1 + p]);
         }
     };
     uint32_t w = 0;
-    for (; w + 16 <= words32; w += 16) chunk(w, std::integral_constant<uint32_t, 16>());
     for (; w + 8 <= words32; w += 8) chunk(w, std::integral_constant<uint32_t, 8>());
     for (; w < words32; ++w) chunk(w, std::integral_constant<uint32_t, 1>());
     uint32_t K = 0;
 #pragma unroll
     for (uint32_t p = 0; p < kRqPlanes; ++p) K += cnt[p] << p;
-    const uint32_t V = reinterpret_cast<const uint32_t *>(r.fsc)[16];
-    const float ip = r.fsc[0] * (float)((int)V - 2 * (int)K);
+    const float delta = __uint_as_float(row[0]), aq = __uint_as_float(row[1]), bq = __uint_as_float(row[2]);
+    const float ip = delta * (float)((int)row[3] - 2 * (int)K);
     const float est = (2.0f - 2.0f * (ip / ipoo)) * norm * qnorm;
-    const float E = norm * (r.fsc[1] + r.fsc[2] / ipoo), round_out = 1e-6f * fabsf(est) + 1e-6f * E;
+    const float E = norm * (aq + bq / ipoo), round_out = 1e-6f * fabsf(est) + 1e-6f * E;
     lb = est - E - round_out;
     return est + E + round_out;
+}
+
+// compute_inner_product_fast for two vectors (see rabitq_ip_pair) whose codes are read from the vector-major copy:
+// ra / rb = the vectors' rows of `vm_words` u32 (a multiple of 4, zero padded), 16-byte aligned.
+__device__ __forceinline__ void rabitq_ip_pair_rows(const uint4 *ra, const uint4 *rb, uint32_t dim, uint32_t words32,
+                                                    const LdsF32 *la, const LdsU32 *ls, float &ipa, float &ipb) {
+    v2f sum = {0.f, 0.f};
+    auto word = [&](uint32_t w, uint32_t wa, uint32_t wb) {
+        const uint32_t q = ls[w];
+        uint64_t y = ((uint64_t)__builtin_bitreverse32(q ^ ~wb) << 32) | __builtin_bitreverse32(q ^ ~wa);
+        if (32 * w + 32 <= dim) {
+#pragma unroll
+            for (uint32_t b = 0; b < 32; ++b) {
+                const float m = la[32 * w + b];
+                const v2f t = {rabitq_signed((uint32_t)y, m), rabitq_signed((uint32_t)(y >> 32), m)};
+                sum += t;
+                y <<= 1;
+            }
+        } else {
+            const uint32_t lim = dim > 32 * w ? dim - 32 * w : 0;
+            for (uint32_t b = 0; b < lim; ++b) {
+                const float m = la[32 * w + b];
+                const v2f t = {rabitq_signed((uint32_t)y, m), rabitq_signed((uint32_t)(y >> 32), m)};
+                sum += t;
+                y <<= 1;
+            }
+        }
+    };
+    uint32_t w = 0;
+    for (; w + 8 <= words32; w += 8) { // four 16-byte loads in flight, no condition before their use
+        const uint4 a0 = ra[w / 4], a1 = ra[w / 4 + 1], b0 = rb[w / 4], b1 = rb[w / 4 + 1];
+        word(w, a0.x, b0.x); word(w + 1, a0.y, b0.y); word(w + 2, a0.z, b0.z); word(w + 3, a0.w, b0.w);
+        word(w + 4, a1.x, b1.x); word(w + 5, a1.y, b1.y); word(w + 6, a1.z, b1.z); word(w + 7, a1.w, b1.w);
+    }
+    for (; w < words32; w += 4) { // the padding words of the last piece cover no dimension: word() adds nothing for them
+        const uint4 a0 = ra[w / 4], b0 = rb[w / 4];
+        word(w, a0.x, b0.x); word(w + 1, a0.y, b0.y); word(w + 2, a0.z, b0.z); word(w + 3, a0.w, b0.w);
+    }
+    ipa = sum.x;
+    ipb = sum.y;
 }
 
 // One block per query (block b takes the query scan_tables_kernel ranked b-th by work): estimated
@@ -366,7 +411,7 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
                           uint32_t tstride, uint32_t lcap, uint32_t tcap, uint32_t rerank_k,
                           uint32_t dist_cap, float *gest, uint32_t gest_stride, uint32_t *sel_pos, uint32_t *sel_key,
                           uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count, uint32_t exact_all,
-                          unsigned long long *stats) {
+                          unsigned long long *stats, const uint32_t *__restrict__ qrows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const uint32_t D = ix.dim, W32 = ix.words32;
@@ -394,15 +439,19 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
     uint32_t *isc = reinterpret_cast<uint32_t *>(r.fsc) + 16;
     CUDDLE_STAMP(6, 1);
     if (filtered) {
-        rabitq_quantise_query(r, D, qnorm);
         if (tid == 0) isc[1] = 0; // members
+        // this query's row of quantised magnitudes: a wave-uniform address, so its words are read into scalar registers
+        const uint32_t *row = qrows + (uint64_t)__builtin_amdgcn_readfirstlane(q) * rq_plane_stride(W32);
         for (uint32_t t = w; t < ntiles; t += nw) {
-            const uint32_t tile = s.tiles[t], sl = tile >> 12, i = ((tile & 4095u) << 6) + lane;
-            const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base;
+            // one tile = 64 consecutive vectors of one leaf: everything but the lane's own vector is the same for the wave
+            const uint32_t tile = __builtin_amdgcn_readfirstlane(s.tiles[t]), sl = tile >> 12, i = ((tile & 4095u) << 6) + lane;
+            const uint32_t base = __builtin_amdgcn_readfirstlane(s.lscan[sl]);
+            const uint32_t n = __builtin_amdgcn_readfirstlane(s.lscan[sl + 1]) - base;
+            const uint32_t beg = __builtin_amdgcn_readfirstlane(s.lbeg[sl]);
             if (i < n) {
-                const uint32_t pos = s.lbeg[sl] + i;
+                const uint32_t pos = beg + i;
                 float lb;
-                est_put(base + i, rabitq_bounds(ix.rq_codes + (uint64_t)s.lbeg[sl] * W32, n, i, W32, r, qnorm, ix.rq_norm[pos],
+                est_put(base + i, rabitq_bounds(ix.rq_codes + (uint64_t)beg * W32, n, i, W32, row, qnorm, ix.rq_norm[pos],
                                                 ix.rq_ipoo[pos], lb));
                 glb[base + i] = lb;
             }
@@ -432,12 +481,14 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
             for (uint32_t j = 2 * tid; j < ns; j += 2 * blockDim.x) {
                 const uint32_t ia = r.list[j], ib = r.list[min(j + 1, ns - 1)];
                 const uint32_t sa = scan_slot_of(s.lscan, nl, ia), sb = scan_slot_of(s.lscan, nl, ib);
-                const uint32_t na = s.lscan[sa + 1] - s.lscan[sa], nb = s.lscan[sb + 1] - s.lscan[sb];
                 const uint32_t ka = ia - s.lscan[sa], kb = ib - s.lscan[sb];
                 const uint32_t pa = s.lbeg[sa] + ka, pb = s.lbeg[sb] + kb;
                 float ipa, ipb;
-                rabitq_ip_pair(ix.rq_codes + (uint64_t)s.lbeg[sa] * W32 + ka, na, ix.rq_codes + (uint64_t)s.lbeg[sb] * W32 + kb, nb, D,
-                               W32, (const LdsF32 *)r.rq, (const LdsU32 *)r.qsign, ipa, ipb);
+                // the vector-major copy: one vector's code is 4 * vm_words contiguous bytes (the word-major leaf blocks
+                // would cost one cache line per code word here)
+                rabitq_ip_pair_rows(reinterpret_cast<const uint4 *>(ix.rq_codes_vm + (uint64_t)pa * ix.rq_vm_words),
+                                    reinterpret_cast<const uint4 *>(ix.rq_codes_vm + (uint64_t)pb * ix.rq_vm_words), D, W32,
+                                    (const LdsF32 *)r.rq, (const LdsU32 *)r.qsign, ipa, ipb);
                 est_put(ia, rabitq_estimate_from_ip(ipa, qnorm, ix.rq_norm[pa], ix.rq_ipoo[pa]));
                 if (j + 1 < ns) est_put(ib, rabitq_estimate_from_ip(ipb, qnorm, ix.rq_norm[pb], ix.rq_ipoo[pb]));
             }
