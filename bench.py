@@ -580,6 +580,23 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
                          f"achieved = algorithmic code bytes / mean duration of the scan kernel alone (HIP events around that launch, on every {STAGE_SAMPLE}th search of the timed loop; "
                          f"the candidate-count / block-order kernel before it is stage scan_prep); the timed loop rotates {N_BATCHES} query batches")
     del dev_index_codes_bytes
+    # what the scan's reads alone cost: a kernel that issues exactly the scan's loads (same leaves, same pieces, as many
+    # in flight) and nothing else, timed back to back with the scan kernel on the first batch
+    if world == 1 and not rabitq:
+        try:
+            nqc = min(nq, 4096)  # one chunk per batch
+            rot = torch.stack([b[:nqc] for b in batches]).contiguous()
+            read_ms, scan_ms_same, code_bytes = dev_index.scan_read_ceiling(rot, k, probes, chosen, 5)
+            del rot
+            roofline.update(ceiling_GBps=code_bytes / (read_ms * 1e-3) / 1e9, ceiling_launch_ms=read_ms,
+                            scan_launch_ms_same_run=scan_ms_same, frac_of_ceiling=read_ms / scan_ms_same,
+                            ceiling_queries_per_launch=nqc,
+                            ceiling_note="ceiling = the scan's own reads with no arithmetic, histogram or selection behind them "
+                                         "(scan_read_ceiling_kernel: same grid, block, LDS size, tables and loads); both kernels "
+                                         f"timed with HIP events over 5 rounds of the same {N_BATCHES} rotating batches")
+        except _ffi.CuddleError as e:
+            roofline.update(ceiling_GBps=None, ceiling_note=str(e))
+        dev_index.stage_times()
 
     # routing filter: approximate (matrix-core) distances against the error bound its proof uses
     route_filter = []
@@ -674,7 +691,8 @@ def compact_config(big, wall_s):
             "stage_ms": r["stage_ms_per_step"],
             "roofline": {key: r[key] for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
                                                  "algorithmic_bytes_per_launch", "avg_launch_ms", "rerank_GBps",
-                                                 "code_array_bytes", "code_array_fits_infinity_cache")},
+                                                 "code_array_bytes", "code_array_fits_infinity_cache", "ceiling_GBps",
+                                                 "frac_of_ceiling") if key in r},
             "cpu_baseline": cpu, "wall_s": wall_s}
 
 

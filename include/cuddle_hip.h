@@ -334,6 +334,19 @@ cuddle_status cuddle_route_filter_error(cuddle_index *idx, const float *queries,
                                         uint32_t n_queries, uint32_t dim,
                                         uint32_t probes_per_level, uint32_t level,
                                         float *out_max_ratio, float *out_max_abs);
+/* Measuring aid, no counterpart in the reference: what the leaf scan's memory accesses cost by themselves.
+ * d_queries: [n_batches][n_queries][dim] on the device (1..64 batches of one chunk each). Every batch is routed
+ * once; then `reps` rounds over the batches are timed (HIP events, null stream), first with a kernel that issues
+ * exactly the reads of the Hamming scan - the same 16-byte pieces of the same leaves, as many in flight - and
+ * nothing else, then with the scan kernel itself. Going round several batches keeps a batch's leaves as cold as
+ * they are between a caller's successive searches. *out_read_ms / *out_scan_ms = mean duration of one launch of
+ * either; *out_code_bytes = the code bytes one launch covers on average (candidates x 8 x ceil(dim / 64), what
+ * collect_leaf_candidates reads, hierarchical.rs:591-641). Binary codes of 2, 4, 8, 12, 15, 16 or 24 words;
+ * CUDDLE_ERR_UNSUPPORTED otherwise. Synchronous. */
+cuddle_status cuddle_scan_read_ceiling(cuddle_index *idx, const float *d_queries, uint32_t n_batches,
+                                       uint32_t n_queries, uint32_t dim, uint32_t k,
+                                       uint32_t probes_per_level, uint32_t rerank_factor, uint32_t reps,
+                                       float *out_read_ms, float *out_scan_ms, uint64_t *out_code_bytes);
 /* The same on device pointers, enqueued on `stream` (1..4096 queries per call): d_leaves
  * [n_queries][leaf_stride] and d_leaf_count [n_queries] receive the leaf lists. leaf_stride
  * must be at least cuddle_index_leaf_stride(probes_per_level), the capacity every search with

@@ -6,7 +6,7 @@ import sys
 
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-first = [i for i, r in enumerate(rows) if "binary_quantize_kernel" in r["Kernel_Name"] or "rabitq_query_prep" in r["Kernel_Name"]]
+first = [i for i, r in enumerate(rows) if any(n in r["Kernel_Name"] for n in ("quantize_init_kernel", "binary_quantize_kernel", "rabitq_query_prep"))]
 a, b = first[-2], first[-1]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0

@@ -362,6 +362,22 @@ static ScanKernel scan_kernel_for(uint32_t dim, uint32_t words) {
     }
 }
 
+using CeilingKernel = void (*)(IndexDev, const uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t *);
+
+// The read-only twin of scan_kernel_for()'s instantiation (same PAIRS / TAIL / U); null for the any-width kernel.
+static CeilingKernel ceiling_kernel_for(uint32_t words) {
+    switch (words) {
+    case 2: return scan_read_ceiling_kernel<1, false, CUDDLE_SCAN_U2>;
+    case 4: return scan_read_ceiling_kernel<2, false, 8>;
+    case 8: return scan_read_ceiling_kernel<4, false, 4>;
+    case 12: return scan_read_ceiling_kernel<6, false, 2>;
+    case 15: return scan_read_ceiling_kernel<7, true, 2>;
+    case 16: return scan_read_ceiling_kernel<8, false, 2>;
+    case 24: return scan_read_ceiling_kernel<12, false, 1>;
+    default: return nullptr;
+    }
+}
+
 template <class T>
 static cuddle_status upload(cuddle_index *ix, const T *src, size_t count, T **dst) {
     *dst = nullptr;
@@ -1102,6 +1118,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                                   hipStream_t s, bool feedback = true, bool zero_stats = false, bool init_done = false) {
     const IndexDev &v = ix->dev;
     const uint32_t stats = (flags & CUDDLE_SEARCH_STATS_VARIANT) ? 1u : 0u;
+    if (feedback && stream_capturing(s)) feedback = false; // event queries and copies to the host have no place in a graph
     if (feedback) half_feedback_poll(ix);
     bool used_half = false;
     auto half_on = [&](uint32_t l) { // the level's filter: single-pass half precision unless told or taught otherwise
@@ -1716,6 +1733,85 @@ extern "C" float cuddle_binary_threshold(const float *vectors, uint64_t n, uint3
     for (uint64_t i = 0; i < count; ++i) t += vectors[i];
     total = t;
     return total / (float)count;
+}
+
+extern "C" cuddle_status cuddle_scan_read_ceiling(cuddle_index *idx, const float *d_queries, uint32_t n_batches,
+                                                  uint32_t n_queries, uint32_t dim, uint32_t k, uint32_t probes_per_level,
+                                                  uint32_t rerank_factor, uint32_t reps, float *out_read_ms, float *out_scan_ms,
+                                                  uint64_t *out_code_bytes) {
+    if (!idx) return fail(CUDDLE_ERR_BAD_ARG, "index is null");
+    if (!d_queries || !out_read_ms || !out_scan_ms || !out_code_bytes) return fail(CUDDLE_ERR_BAD_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    ST_TRY(use_device(idx->device));
+    const IndexDev &v = idx->dev;
+    if (dim != v.dim) return fail(CUDDLE_ERR_BAD_DIM, "query dimension %u != index dimension %u", dim, v.dim);
+    if (probes_per_level == 0 || reps == 0 || n_batches == 0 || n_batches > 64)
+        return fail(CUDDLE_ERR_BAD_ARG, "probes_per_level and reps must be >= 1, 1..64 batches");
+    CeilingKernel ck = v.code_kind == CUDDLE_CODE_BINARY ? ceiling_kernel_for(v.words) : nullptr;
+    if (!ck) return fail(CUDDLE_ERR_UNSUPPORTED, "no read-only twin for this code (binary codes of 2, 4, 8, 12, 15, 16 or 24 words)");
+    uint64_t rerank_k;
+    ST_TRY(rerank_k_of(k, rerank_factor, 0, rerank_k));
+    ST_TRY(enter_stream(idx, nullptr));
+    idx->timed = false;
+    idx->shard_state = 0;
+    Plan pl;
+    ST_TRY(make_plan(idx, n_queries, k, probes_per_level, rerank_k, 0, pl));
+    if (n_queries == 0 || n_queries > pl.qc) return fail(CUDDLE_ERR_BAD_ARG, "1..%u queries per batch (one chunk)", pl.qc);
+    (void)hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipStream_t s = nullptr;
+    // every batch is routed once; its blocks' tables and its query codes are kept aside, so that the timed launches can
+    // go round the batches as a caller's successive searches would (a batch's leaves are cold again when its turn comes)
+    const uint32_t tstride = pl.lstride + 4;
+    const size_t tbytes = align_up((size_t)n_queries * 4 * tstride * 4, 256), qbytes = align_up((size_t)n_queries * v.words * 8, 256);
+    TmpDev keep;
+    ST_TRY(keep.alloc((tbytes + qbytes) * n_batches));
+    char *kb = static_cast<char *>(keep.p);
+    uint64_t total = 0;
+    std::vector<uint32_t> cc(n_queries);
+    for (uint32_t b = 0; b < n_batches; ++b) {
+        const float *q = d_queries + (uint64_t)b * n_queries * dim;
+        ST_TRY(launch_quantize(idx, pl, q, n_queries, s));
+        ST_TRY(launch_route(idx, pl, q, n_queries, 0, s, false, true));
+        ST_TRY(launch_scan_select(idx, pl, n_queries, s)); // also leaves the blocks' tables in pl.leaf_tables
+        HIP_TRY(hipMemcpyAsync(kb + (tbytes + qbytes) * b, pl.leaf_tables, (size_t)n_queries * 4 * tstride * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(kb + (tbytes + qbytes) * b + tbytes, pl.qcodes, (size_t)n_queries * v.words * 8, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpy(cc.data(), pl.cand_count, (size_t)n_queries * 4, hipMemcpyDeviceToHost));
+        for (uint32_t c : cc) total += c;
+    }
+    hipEvent_t ev[3];
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    auto tables_of = [&](uint32_t b) { return reinterpret_cast<const uint32_t *>(kb + (tbytes + qbytes) * b); };
+    auto codes_of = [&](uint32_t b) { return reinterpret_cast<const uint64_t *>(kb + (tbytes + qbytes) * b + tbytes); };
+    auto read_once = [&](uint32_t b) {
+        hipLaunchKernelGGL(ck, dim3(n_queries), dim3(pl.scan_threads), pl.scan_lds, s, v, tables_of(b), tstride, pl.lstride, pl.tcap, pl.sel_count);
+    };
+    auto scan_once = [&](uint32_t b) {
+        hipLaunchKernelGGL(scan_kernel_for(v.dim, v.words), dim3(n_queries), dim3(pl.scan_threads), pl.scan_lds, s, v, codes_of(b),
+                           tables_of(b), tstride, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, (void *)pl.gdist, pl.cstride,
+                           pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, (uint32_t *)nullptr);
+    };
+    auto body = [&]() -> cuddle_status {
+        for (uint32_t b = 0; b < n_batches; ++b) read_once(b); // one untimed round
+        HIP_TRY(hipEventRecord(ev[0], s));
+        for (uint32_t r = 0; r < reps; ++r)
+            for (uint32_t b = 0; b < n_batches; ++b) read_once(b);
+        HIP_TRY(hipEventRecord(ev[1], s));
+        for (uint32_t r = 0; r < reps; ++r)
+            for (uint32_t b = 0; b < n_batches; ++b) scan_once(b);
+        HIP_TRY(hipEventRecord(ev[2], s));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventSynchronize(ev[2]));
+        float a = 0.f, bms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&bms, ev[1], ev[2]));
+        *out_read_ms = a / (float)(reps * n_batches);
+        *out_scan_ms = bms / (float)(reps * n_batches);
+        *out_code_bytes = total * 8ull * v.words / n_batches;
+        return CUDDLE_OK;
+    };
+    const cuddle_status st = body();
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return st;
 }
 
 extern "C" cuddle_status cuddle_route_batch(cuddle_index *idx, const float *queries, uint32_t n_queries, uint32_t dim,

@@ -1242,6 +1242,66 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
     }
 }
 
+// Measuring aid: the memory side of scan_select_hamming_kernel and nothing else. Same grid, block, LDS size and
+// prologue (the block's tables, its tile list), and exactly the scan's loads - the same 16-byte pieces of the same
+// leaves, U tiles in flight per wave - but no XOR / popcount, no histogram, no distance stores, no selection: the
+// loaded words are folded into one register, which is stored only if it equals a value it practically never has
+// (so that the loads stay). Its duration is what the access pattern costs; the scan's excess over it is arithmetic
+// and selection.
+template <int PAIRS, bool TAIL, int U>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((PAIRS == 1 && !TAIL) ? 8 : 1)))
+scan_read_ceiling_kernel(IndexDev ix, const uint32_t *tables, uint32_t tstride, uint32_t lcap, uint32_t tcap, uint32_t *sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    ScanLds s = scan_lds_carve(smem, ix.dim, ix.words, lcap, tcap, PAIRS == 1 && !TAIL);
+    uint32_t ntiles = 0, q, nl;
+    scan_copy_tables(s, tables + (uint64_t)blockIdx.x * 4 * tstride, tstride, lcap, &q, &nl);
+    const uint32_t C = scan_build_tiles(s, nl, tcap, &ntiles);
+    if (C == 0) return;
+    uint32_t acc = 0;
+    if (PAIRS == 1 && !TAIL) {
+        for (uint32_t t0 = w * U; t0 < ntiles; t0 += nw * U) {
+            uint4 c[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t t = t0 + u;
+                const uint32_t ti = t < ntiles ? s.tinfo[t] : 0u;
+                const uint32_t co = s.tcode[t < ntiles ? t : t0];
+                c[u] = lane < (ti & 127u) ? ix.codes[(uint64_t)co + lane] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc ^= c[u].x ^ c[u].y ^ c[u].z ^ c[u].w;
+        }
+    } else {
+        for (uint32_t t0 = w * U; t0 < ntiles; t0 += nw * U) {
+            uint4 c[U][PAIRS > 0 ? PAIRS : 1];
+            uint2 ct[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t t = t0 + u;
+                const uint32_t tile = s.tiles[t < ntiles ? t : t0];
+                const uint32_t sl = tile >> 12, i = ((tile & 4095u) << 6) + lane;
+                const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base;
+                const bool act = t < ntiles && i < n;
+                const uint4 *planes = ix.codes + s.lcode[sl];
+#pragma unroll
+                for (int p = 0; p < PAIRS; ++p) c[u][p] = act ? planes[(uint64_t)p * n + i] : make_uint4(0, 0, 0, 0);
+                if (TAIL) {
+                    const uint2 *tail = reinterpret_cast<const uint2 *>(planes + (uint64_t)PAIRS * n);
+                    ct[u] = act ? tail[i] : make_uint2(0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int p = 0; p < PAIRS; ++p) acc ^= c[u][p].x ^ c[u][p].y ^ c[u][p].z ^ c[u][p].w;
+                if (TAIL) acc ^= ct[u].x ^ ct[u].y;
+            }
+        }
+    }
+    if (acc == 0x9E3779B9u && sink) sink[q] = acc;
+}
+
 // collect_leaf_candidates (hierarchical.rs:618-641) written out in full: every candidate's
 // leaf-contiguous position and Hamming distance in scan order. Stage entry point for parity tests.
 __global__ void __launch_bounds__(256)

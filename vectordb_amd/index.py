@@ -346,6 +346,18 @@ class DeviceIndex:
                                                        _ffi.ptr(ratio), _ffi.ptr(err)))
         return float(ratio[0]), float(err[0])
 
+    def scan_read_ceiling(self, d_batches, k: int, probes_per_level: int, rerank_factor: int, reps: int = 5):
+        """d_batches: float32 CUDA tensor [n_batches, nq, dim]. (read_ms, scan_ms, code_bytes): mean launch time of the
+        kernel that only issues the Hamming scan's reads, of the scan kernel itself (both going round the batches
+        `reps` times), and the code bytes one launch covers (cuddle_scan_read_ceiling)."""
+        assert d_batches.is_cuda and d_batches.is_contiguous() and d_batches.dim() == 3
+        nb, nq, dim = d_batches.shape
+        a, b = np.zeros(1, dtype=np.float32), np.zeros(1, dtype=np.float32)
+        n = np.zeros(1, dtype=np.uint64)
+        _ffi.check(self._lib.cuddle_scan_read_ceiling(self._handle, C.c_void_p(d_batches.data_ptr()), nb, nq, dim, k,
+                                                      probes_per_level, rerank_factor, reps, _ffi.ptr(a), _ffi.ptr(b), _ffi.ptr(n)))
+        return float(a[0]), float(b[0]), int(n[0])
+
     def scan_batch(self, queries: np.ndarray, leaves: np.ndarray, leaf_count: np.ndarray):
         q = np.ascontiguousarray(queries, dtype=np.float32)
         nq, dim = q.shape
