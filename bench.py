@@ -417,7 +417,12 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
 
     exact = world > 1 and args.sharded == "exact"
     # CUDDLE_BENCH_SHARD_ROUTING=0: every rank routes the whole batch (A/B against routing a slice each + all-gather)
-    searcher = (ExactShardedSearcher(_ShardEngine(), shard_routing=os.environ.get("CUDDLE_BENCH_SHARD_ROUTING", "1") != "0")
+    clock = None
+    if exact:
+        from vectordb_amd.sharded import CommClock
+        clock = CommClock()  # every collective of the protocol timed by name (HIP events on the stream / host clock under gloo)
+    searcher = (ExactShardedSearcher(_ShardEngine(), shard_routing=os.environ.get("CUDDLE_BENCH_SHARD_ROUTING", "1") != "0",
+                                     hist_exchange=args.hist_exchange, clock=clock)
                 if exact else ShardedSearcher(local_search))
     if exact and args.collectives == "cabi":
         # the same protocol with RCCL called by the library (cuddle_comm_* / cuddle_sharded_search_batch); the id
@@ -477,6 +482,8 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
     for _ in range(warmup):
         step()
     dev_index.stage_times()
+    if clock is not None:
+        clock.reset()
     step_no[0] = 0  # the timed region starts on a sampled search
     if world > 1:
         dist.barrier()
@@ -496,6 +503,14 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
         elapsed = float(te.item())
     stage = dev_index.stage_times()
     stats = dev_index.last_stats()
+    comm = None
+    if clock is not None and args.collectives == "torch":
+        # this rank's collectives over the timed region: milliseconds per call, bytes this rank contributes per call
+        comm = {"per_collective": clock.summary(), "hist_exchange": args.hist_exchange,
+                "note": "rank 0's view; ms_per_call includes waiting for the slowest rank to arrive"}
+        comm["ms_per_step"] = sum(v["ms_per_call"] * v["calls"] for v in comm["per_collective"].values()) / max(steps, 1)
+        clock.reset()
+        clock = searcher.clock = None  # the loops below run untimed
 
     # per-batch latency distribution (separate loop: one sync per batch), at least 200 samples
     lat = []
@@ -658,6 +673,7 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
         "recall_sweep": sweep,
         "host_pointer_entry": host_entry,
         "one_batch_split": one_batch,
+        "comm_ms": comm,
         "reference_threshold": ref_threshold,
         "p50_batch_ms": lat[len(lat) // 2],
         "p99_batch_ms": lat[min(len(lat) - 1, len(lat) * 99 // 100)],
@@ -716,6 +732,9 @@ def main():
                          "default); fixed = the config's one batch split over the ranks (strong scaling)")
     ap.add_argument("--collectives", default="torch", choices=["torch", "cabi"],
                     help="N > 1, exact: who calls the collectives - torch.distributed (default) or the library itself through cuddle_comm_*")
+    ap.add_argument("--hist-exchange", default="auto", choices=["auto", "full", "coarse_fine"],
+                    help="N > 1, exact, binary codes: how the Hamming histograms travel - whole ([Q][dim + 1] u32), or in bins of 16 "
+                         "values and then the 16 values of the threshold's bin (two small all-reduces); auto = the latter from 256 bins on")
     ap.add_argument("--sharded", default="exact", choices=["exact", "simple"],
                     help="N > 1: 'exact' reproduces the single-index result bit for bit (two small all-reduces + one "
                          "all-gather per batch); 'simple' lets every rank rerank its own top candidates (one all-gather)")

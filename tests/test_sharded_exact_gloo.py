@@ -170,19 +170,22 @@ class OracleShardEngine:
 CASES = {"tight": (10, 4, 3), "mid": (10, 6, 10), "one": (1, 2, 1), "covering": (10, 4, 1000)}
 
 
-def _worker(rank, world, port, out_path, code_kind="binary"):
+def _worker(rank, world, port, out_path, code_kind="binary", d=16):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from vectordb_amd.sharded import ExactShardedSearcher
+        from vectordb_amd.sharded import CommClock, ExactShardedSearcher
 
-        x, fi = small_index(n=4000, d=16, n_clusters=20, branching=6, leaf=30, code_kind=code_kind)
+        x, fi = small_index(n=4000, d=d, n_clusters=20, branching=6, leaf=30, code_kind=code_kind)
         q = queries_like(x, 24, 9)
         engine = OracleShardEngine(fi.shard(rank, world))
-        searcher = ExactShardedSearcher(engine)
+        searcher = ExactShardedSearcher(engine, hist_exchange="full")
         assert searcher.world == world and searcher.rank == rank and searcher.shard_routing
         plain = ExactShardedSearcher(OracleShardEngine(fi.shard(rank, world)), shard_routing=False)
+        # the two-step histogram exchange (bins of 16, then the 16 values of the threshold's bin), with every collective timed
+        clock = CommClock()
+        coarse = ExactShardedSearcher(OracleShardEngine(fi.shard(rank, world)), hist_exchange="coarse_fine", clock=clock)
         res = {}
         for name, (k, probes, rf) in CASES.items():
             ids, dd, cnt = searcher.search_batch(torch.from_numpy(q), k, probes, rf)
@@ -190,23 +193,33 @@ def _worker(rank, world, port, out_path, code_kind="binary"):
             assert engine.given and engine.routed == max(0, min(per, q.shape[0] - rank * per))  # routed only its slice
             ids2, dd2, cnt2 = plain.search_batch(torch.from_numpy(q), k, probes, rf)  # every rank routing everything
             assert torch.equal(ids, ids2) and torch.equal(dd, dd2) and torch.equal(cnt, cnt2)
+            ids3, dd3, cnt3 = coarse.search_batch(torch.from_numpy(q), k, probes, rf)
+            assert torch.equal(ids, ids3) and torch.equal(dd, dd3) and torch.equal(cnt, cnt3), name
             res[name] = (ids.numpy().copy(), dd.numpy().copy(), cnt.numpy().copy())
             t = torch.from_numpy(res[name][0].copy())
             dist.broadcast(t, src=0)
             assert torch.equal(t, torch.from_numpy(res[name][0])), f"rank {rank} differs from rank 0 ({name})"
+        timed = clock.summary()
+        if code_kind == "binary":
+            assert set(timed) == {"leaf_gather", "hist_coarse_allreduce", "hist_fine_allreduce", "tie_allreduce", "result_gather"}, timed
+            assert timed["hist_coarse_allreduce"]["bytes_per_call"] == q.shape[0] * ((d + 1 + 15) // 16) * 4
+            assert timed["hist_fine_allreduce"]["bytes_per_call"] == q.shape[0] * 16 * 4
+        else:
+            assert set(timed) == {"leaf_gather", "key_gather", "result_gather"}, timed
+        assert all(v["calls"] == len(CASES) and v["ms_per_call"] >= 0 for v in timed.values())
         if rank == 0:
             np.savez(out_path, q=q, **{f"{n}_{f}": v for n, r in res.items() for f, v in zip(("ids", "dist", "cnt"), r)})
     finally:
         dist.destroy_process_group()
 
 
-def _run(world, tmp_path, code_kind="binary"):
+def _run(world, tmp_path, code_kind="binary", d=16):
     from oracle import oracle as orc
 
     out = str(tmp_path / f"exact{world}.npz")
-    mp.spawn(_worker, args=(world, _free_port(), out, code_kind), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, code_kind, d), nprocs=world, join=True)
     z = np.load(out)
-    x, fi = small_index(n=4000, d=16, n_clusters=20, branching=6, leaf=30, code_kind=code_kind)
+    x, fi = small_index(n=4000, d=d, n_clusters=20, branching=6, leaf=30, code_kind=code_kind)
     full = orc.OracleIndex(fi)
     for name, (k, probes, rf) in CASES.items():
         rc, ids, dd, cnt = full.search_batch(z["q"], k, probes, rf)
@@ -227,3 +240,8 @@ def test_three_rank_exact_sharded_search(tmp_path):
 def test_two_rank_exact_sharded_search_rabitq(tmp_path):
     """RaBitQ codes: one all-gather of selection keys instead of the two all-reduces."""
     _run(2, tmp_path, "rabitq")
+
+
+def test_two_rank_coarse_then_fine_histograms_wider_codes(tmp_path):
+    """71 Hamming values = 5 coarse bins: the threshold's bin lies in the middle, candidates below it are lumped."""
+    _run(2, tmp_path, d=70)

@@ -83,6 +83,11 @@ struct cuddle_comm {
     int rank = 0, world = 1, device = 0;
     DevBuf buf; // messages of one batch
     std::mutex mu;
+    // Before the first data collective of a batch shape the ranks agree that every one of them can run it (see
+    // sharded_preflight): the agreement is remembered for the shape it was made for.
+    uint32_t *d_agree = nullptr; // [4] device words of the agreement all-reduce
+    uint64_t agreed_shape = 0;
+    const cuddle_index *agreed_shard = nullptr;
 };
 
 static_assert(CUDDLE_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id travels as an opaque byte array of RCCL's size");
@@ -112,6 +117,12 @@ extern "C" cuddle_status cuddle_comm_init(int rank, int world, const uint8_t *id
         delete c;
         return fail(CUDDLE_ERR_RCCL, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl_api().GetErrorString(r));
     }
+    if (hipMalloc((void **)&c->d_agree, 16) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)rccl_api().CommDestroy(c->comm);
+        delete c;
+        return fail(CUDDLE_ERR_OOM, "hipMalloc(16) failed");
+    }
     *out = c;
     return CUDDLE_OK;
 }
@@ -121,12 +132,61 @@ extern "C" void cuddle_comm_destroy(cuddle_comm *c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     if (c->comm) (void)rccl_api().CommDestroy(c->comm);
+    if (c->d_agree) (void)hipFree(c->d_agree);
     c->buf.release();
     delete c;
 }
 
 extern "C" int cuddle_comm_rank(const cuddle_comm *c) { return c ? c->rank : -1; }
 extern "C" int cuddle_comm_world(const cuddle_comm *c) { return c ? c->world : 0; }
+
+// Everything about a batch shape that can fail on ONE rank only - limits that depend on the rank's own shard (its
+// leaf sizes decide whether the chunk fits the work-space budget, the candidate bound, the scan's LDS), growing the
+// work space or the message buffer - is tried here, before any data travels, and the ranks then agree on the outcome
+// with one small all-reduce: a rank that left the protocol on its own would leave its peers waiting in the next
+// collective for good. Also checked: every rank uses the same leaf-list stride (the messages are laid out by it).
+// The agreement costs a host wait, so it is made once per (shard, batch shape) and remembered.
+static cuddle_status sharded_preflight(cuddle_index *shard, cuddle_comm *comm, uint32_t nq, uint32_t k, uint32_t probes,
+                                       uint32_t rerank_factor, uint32_t flags, uint32_t lstride, size_t msg_bytes, hipStream_t s) {
+    const uint64_t shape = ((uint64_t)nq << 40) ^ ((uint64_t)k << 28) ^ ((uint64_t)probes << 14) ^ ((uint64_t)rerank_factor << 3) ^ flags;
+    if (comm->agreed_shard == shard && comm->agreed_shape == shape && msg_bytes <= comm->buf.bytes) return CUDDLE_OK;
+    RcclApi &api = rccl_api();
+    cuddle_status local = CUDDLE_OK;
+    std::string local_msg;
+    {
+        uint64_t rerank_k = 0;
+        local = rerank_k_of(k, rerank_factor, flags, rerank_k);
+        if (local == CUDDLE_OK) {
+            std::lock_guard<std::mutex> lk(shard->mu);
+            Plan route_plan, scan_plan;
+            local = make_plan(shard, nq, 1, probes, 1, 0, route_plan);
+            if (local == CUDDLE_OK && route_plan.qc < nq)
+                local = fail(CUDDLE_ERR_UNSUPPORTED, "%u queries do not fit the work-space budget in one chunk (%u do)", nq, route_plan.qc);
+            if (local == CUDDLE_OK) local = make_plan(shard, nq, k, probes, rerank_k, 0, scan_plan, nullptr, 0, /*whole_index=*/false);
+            if (local == CUDDLE_OK && scan_plan.qc < nq)
+                local = fail(CUDDLE_ERR_UNSUPPORTED, "%u queries do not fit the work-space budget in one chunk (%u do)", nq, scan_plan.qc);
+            if (local == CUDDLE_OK && shard->dev.code_kind == CUDDLE_CODE_RABITQ && scan_plan.lstride >= (1u << kRqSlotBits))
+                local = fail(CUDDLE_ERR_UNSUPPORTED, "leaf lists of %u slots: the key holds %u bits", scan_plan.lstride, kRqSlotBits);
+        }
+        if (local == CUDDLE_OK) local = comm->buf.ensure(msg_bytes);
+        if (local != CUDDLE_OK) local_msg = g_last_error;
+    }
+    // max over the ranks of (status, stride, ~stride): any failure shows, and so do two different strides
+    const uint32_t h[4] = {(uint32_t)local, lstride, ~lstride, 0u};
+    uint32_t g[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(comm->d_agree, h, 16, hipMemcpyHostToDevice, s));
+    RCCL_TRY(api.AllReduce(comm->d_agree, comm->d_agree, 4, ncclUint32, ncclMax, comm->comm, s));
+    HIP_TRY(hipMemcpyAsync(g, comm->d_agree, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (local != CUDDLE_OK) return fail(local, "%s", local_msg.c_str());
+    if (g[0] != CUDDLE_OK)
+        return fail((cuddle_status)g[0], "another rank cannot run this batch on its shard (status %u there); no rank has started it", g[0]);
+    if (g[1] != lstride || ~g[2] != lstride)
+        return fail(CUDDLE_ERR_BAD_INDEX, "the ranks' trees differ: leaf-list strides %u..%u for probes_per_level %u", ~g[2], g[1], probes);
+    comm->agreed_shard = shard;
+    comm->agreed_shape = shape;
+    return CUDDLE_OK;
+}
 
 // One round of the protocol for at most kMaxChunk queries (the caller holds comm->mu and has made the device current).
 static cuddle_status sharded_search_chunk(cuddle_index *shard, cuddle_comm *comm, const float *d_queries, uint32_t n_queries,
@@ -152,7 +212,8 @@ static cuddle_status sharded_search_chunk(cuddle_index *shard, cuddle_comm *comm
                  o_lc = carve((size_t)world * per * 4), o_hist = carve(rabitq ? 0 : (size_t)nq * (D + 1) * 4),
                  o_ties = carve(rabitq ? 0 : (size_t)nq * lstride * 4), o_rmine = carve(res_words * 8), o_rall = carve(res_words * 8 * world),
                  o_kmine = carve(key_words * 8), o_kall = carve(key_words * 8 * world);
-    ST_TRY(comm->buf.ensure(off));
+    // shard-local checks and allocations first, agreed on by all ranks: nothing below may fail on one rank alone
+    ST_TRY(sharded_preflight(shard, comm, nq, k, probes_per_level, rerank_factor, flags, lstride, off, s));
     char *b = static_cast<char *>(comm->buf.p);
     uint32_t *l_mine = (uint32_t *)(b + o_lmine), *l_all = (uint32_t *)(b + o_lall), *lv = (uint32_t *)(b + o_lv), *lc = (uint32_t *)(b + o_lc);
     uint32_t *hist = (uint32_t *)(b + o_hist), *ties = (uint32_t *)(b + o_ties);

@@ -77,6 +77,47 @@ def _all_gather(out: torch.Tensor, mine: torch.Tensor, group) -> None:
         dist.all_gather(list(out.unbind(0)), mine, group=group)
 
 
+class CommClock:
+    """Time and bytes of every collective of the sharded protocol, by name: HIP events on the current stream around
+    the call for RCCL (the call makes the stream wait for the collective), the host clock for the staged gloo
+    rehearsals. `summary()` gives, per name, calls, milliseconds per call and bytes this rank sends per call."""
+
+    def __init__(self):
+        self.pending = []   # (name, start event, end event)
+        self.ms = {}
+        self.calls = {}
+        self.bytes = {}
+
+    def run(self, name: str, nbytes: int, fn, tensor: torch.Tensor, group):
+        self.calls[name] = self.calls.get(name, 0) + 1
+        self.bytes[name] = nbytes
+        if tensor.is_cuda and not _via_host(group):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            self.pending.append((name, e0, e1))
+        else:
+            import time
+            if tensor.is_cuda:
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            self.ms[name] = self.ms.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+
+    def summary(self) -> dict:
+        if self.pending:
+            torch.cuda.synchronize()
+            for name, e0, e1 in self.pending:
+                self.ms[name] = self.ms.get(name, 0.0) + e0.elapsed_time(e1)
+            self.pending = []
+        return {n: {"calls": c, "ms_per_call": self.ms.get(n, 0.0) / c, "bytes_per_call": self.bytes[n]} for n, c in self.calls.items()}
+
+    def reset(self):
+        self.summary()
+        self.ms, self.calls, self.bytes = {}, {}, {}
+
+
 class ShardedSearcher:
     """search_batch over `world` leaf shards. `local_search(queries, k, probes, rerank_factor)` must
     return (ids int64 [nq,k], dist f32 [nq,k], count) tensors on the collective's device; on the
@@ -161,7 +202,19 @@ class ExactShardedSearcher:
     shard_finish(queries, global_ties) -> (ids, dist, order, count) as tensors on the collective's
     device (`DeviceIndex` on the GPU)."""
 
-    def __init__(self, engine, group: Optional[dist.ProcessGroup] = None, shard_routing: bool = True):
+    COARSE_BIN = 16        # Hamming values per coarse bin of the two-step histogram exchange
+    COARSE_MIN_BINS = 256  # "auto": histograms of at least this many bins travel coarse first
+
+    def __init__(self, engine, group: Optional[dist.ProcessGroup] = None, shard_routing: bool = True,
+                 hist_exchange: str = "auto", clock: Optional[CommClock] = None):
+        """hist_exchange: how the ranks agree on the Hamming threshold. "full": one all-reduce of the [nq, dim + 1]
+        histograms (the protocol's one message that grows with the dimension: 31 MB for 8000 queries of 960-d).
+        "coarse_fine": an all-reduce of the histograms in bins of 16 values, then one of the 16 values of the bin
+        the threshold falls in - the same threshold and tie budget from two small messages. "auto": coarse_fine
+        from 256 bins on. clock: a CommClock that times every collective (None: no timing, no events)."""
+        assert hist_exchange in ("auto", "full", "coarse_fine")
+        self.hist_exchange = hist_exchange
+        self.clock = clock
         self.engine = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -171,6 +224,52 @@ class ExactShardedSearcher:
         self.shard_routing = shard_routing and self.world > 1 and hasattr(engine, "route_device")
         # engines that can write their outputs into caller-given message buffers (DeviceIndex) save the packing copies
         self.packed = hasattr(engine, "packed_len")
+
+    def _gather(self, name: str, out: torch.Tensor, mine: torch.Tensor):
+        if self.clock is None:
+            _all_gather(out, mine, self.group)
+        else:
+            self.clock.run(name, mine.numel() * mine.element_size(), lambda: _all_gather(out, mine, self.group), mine, self.group)
+
+    def _reduce(self, name: str, t: torch.Tensor):
+        if self.clock is None:
+            _all_reduce_sum(t, self.group)
+        else:
+            self.clock.run(name, t.numel() * t.element_size(), lambda: _all_reduce_sum(t, self.group), t, self.group)
+
+    def _global_histogram(self, hist: torch.Tensor, rerank_k: int) -> torch.Tensor:
+        """The sum of the ranks' [nq, bins] histograms, or a stand-in that gives cuddle_shard_ties the same threshold
+        and tie budget: those depend on the running sums only, so everything below the coarse bin in which the
+        rerank_k-th candidate falls may sit in one earlier bin, and what lies above it is never looked at."""
+        nq, bins = hist.shape
+        mode = self.hist_exchange
+        if mode == "auto":
+            mode = "coarse_fine" if bins >= self.COARSE_MIN_BINS else "full"
+        if mode == "full" or self.world == 1:
+            if self.world > 1:
+                self._reduce("hist_allreduce", hist)
+            return hist
+        B = self.COARSE_BIN
+        nb = (bins + B - 1) // B
+        padded = torch.zeros((nq, nb * B), dtype=hist.dtype, device=hist.device)
+        padded[:, :bins] = hist
+        local = padded.view(nq, nb, B)
+        coarse = local.sum(dim=2, dtype=torch.int64).to(torch.int32).contiguous()
+        self._reduce("hist_coarse_allreduce", coarse)
+        cum = coarse.to(torch.int64).cumsum(dim=1)
+        reached = cum >= rerank_k
+        # the first coarse bin whose running sum reaches rerank_k; none (fewer candidates than that): the last bin
+        c0 = torch.where(reached.any(dim=1), reached.to(torch.int8).argmax(dim=1), torch.full((nq,), nb - 1, device=hist.device))
+        rows = torch.arange(nq, device=hist.device)
+        below = (cum[rows, c0] - coarse[rows, c0].to(torch.int64)).to(torch.int32)
+        fine = local[rows, c0].contiguous()  # [nq, B]: this rank's counts of the bin's values
+        self._reduce("hist_fine_allreduce", fine)
+        out = torch.zeros((nq, nb * B), dtype=hist.dtype, device=hist.device)
+        cols = c0[:, None] * B + torch.arange(B, device=hist.device)[None, :]
+        out.scatter_(1, cols, fine)
+        has_below = c0 > 0
+        out[rows[has_below], (c0[has_below] * B - 1)] = below[has_below]
+        return out[:, :bins].contiguous()
 
     def _route_sharded(self, queries: torch.Tensor, probes_per_level: int):
         nq = queries.shape[0]
@@ -189,13 +288,17 @@ class ExactShardedSearcher:
             mine[:q1 - q0, :stride] = leaves
             mine[:q1 - q0, stride] = count
         everyone = torch.empty((self.world, per, stride + 1), dtype=mine.dtype, device=mine.device)
-        _all_gather(everyone, mine, self.group)
+        self._gather("leaf_gather", everyone, mine)
         everyone = everyone.reshape(self.world * per, stride + 1)[:nq]  # rows past a rank's slice lie past nq
         if self.packed:
             return everyone[:, :stride], everyone[:, stride].contiguous()  # the lists stay where the gather put them
         return everyone[:, :stride].contiguous(), everyone[:, stride].contiguous()
 
     MAX_ROUND = 4096  # queries per round of the protocol (the library's limit for one sharded batch)
+
+    @staticmethod
+    def _rerank_k(k: int, rerank_factor: int) -> int:
+        return min(k * rerank_factor, 10000)  # search() caps the selection (hierarchical.rs:447)
 
     def search_batch(self, queries: torch.Tensor, k: int, probes_per_level: int, rerank_factor: int):
         """Larger batches run as equal rounds of at most MAX_ROUND queries, one after the other (every rank cuts
@@ -218,18 +321,17 @@ class ExactShardedSearcher:
             keys = self.engine.shard_scan_keys(queries, k, probes_per_level, rerank_factor, leaves=leaves, leaf_count=count)
             all_keys = torch.empty((self.world,) + tuple(keys.shape), dtype=keys.dtype, device=keys.device)
             if self.world > 1:
-                _all_gather(all_keys, keys, self.group)
+                self._gather("key_gather", all_keys, keys)
             else:
                 all_keys[0] = keys
             finish = lambda **kw: self.engine.shard_finish_keys(queries, all_keys, **kw)  # noqa: E731
         else:
             hist = self.engine.shard_scan(queries, k, probes_per_level, rerank_factor, leaves=leaves, leaf_count=count) \
                 if leaves is not None else self.engine.shard_scan(queries, k, probes_per_level, rerank_factor)
-            if self.world > 1:
-                _all_reduce_sum(hist, self.group)
+            hist = self._global_histogram(hist, self._rerank_k(k, rerank_factor))
             ties = self.engine.shard_ties(hist)
             if self.world > 1:
-                _all_reduce_sum(ties, self.group)
+                self._reduce("tie_allreduce", ties)
             finish = lambda **kw: self.engine.shard_finish(queries, ties, **kw)  # noqa: E731
         if self.packed and self.world > 1:
             nq = queries.shape[0]
@@ -237,7 +339,7 @@ class ExactShardedSearcher:
             mine = torch.empty((words,), dtype=torch.int64, device=queries.device)
             finish(packed=mine)
             everyone = torch.empty((self.world, words), dtype=torch.int64, device=queries.device)
-            _all_gather(everyone, mine, self.group)
+            self._gather("result_gather", everyone, mine)
             return merge_gathered_packed(everyone, nq, k)
         ids, dist_, order, count = finish()
         if self.world == 1:
@@ -246,7 +348,7 @@ class ExactShardedSearcher:
         # one message per rank: [3][nq][k] int64 = ids, order keys, distance bits
         mine = torch.stack((ids, order, dist_.contiguous().view(torch.int32).to(torch.int64)))
         everyone = torch.empty((self.world, 3, nq, k), dtype=torch.int64, device=ids.device)
-        _all_gather(everyone, mine, self.group)
+        self._gather("result_gather", everyone, mine)
         all_dist = everyone[:, 2].to(torch.int32).view(torch.float32)
         return merge_gathered_ordered(everyone[:, 0], all_dist, everyone[:, 1], k)
 
