@@ -23,6 +23,7 @@
 #include "cuddle_route.hpp"
 #include "cuddle_shard.hpp"
 #include "cuddle_rabitq.hpp"
+#include "cuddle_rabitq_grouped.hpp"
 #include "cuddle_build.hpp"
 
 using namespace cuddle;
@@ -186,6 +187,7 @@ struct DevStats { // accumulated on device by stats_accum_kernel
     unsigned long long leaves, scanned, reranked;
     uint32_t max_cand, max_leaves, fallbacks, pad1;
     unsigned long long rq_exact, rq_exact_all; // RaBitQ scan: candidates evaluated exactly, queries that evaluated all of theirs
+    unsigned long long rq_mismatch;            // ... bounds of the grouped kernel that differ from the per-query ones (checking mode)
 };
 
 // Work-space layout of one chunk of queries.
@@ -216,6 +218,12 @@ struct Plan {
     uint64_t *sel_ord = nullptr;
     float *qnorm = nullptr; // cosine: sqrt(dot(q, q)) per query
     uint32_t *rq_rows = nullptr; // RaBitQ: [qc][rq_plane_stride] quantised query magnitudes as bit planes (rabitq_query_planes_kernel)
+    // RaBitQ bounds on the matrix cores (rq_bounds_grouped_kernel): the queries' signed pieces, the (query, leaf) pairs
+    // of the leaf lists in leaf order, the work items cut from them
+    int8_t *rq_i8 = nullptr;
+    uint32_t *rq_pinfo = nullptr, *rq_pnode = nullptr, *rq_pslot = nullptr, *rq_psorted = nullptr;
+    uint32_t *rq_cnt = nullptr, *rq_poff = nullptr, *rq_ioff = nullptr, *rq_bsum = nullptr, *rq_items = nullptr;
+    bool rq_grouped = false;
     uint32_t *level_fc = nullptr; // [n_levels + 1][qc] frontier size of every query at every level (stats variant)
     uint32_t *leaf_tables = nullptr; // [qc][4][lstride + 4] per-slot tables of the reached leaves (cand_count_kernel)
     uint32_t *sel_pos = nullptr, *sel_key = nullptr, *sel_count = nullptr, *cand_count = nullptr;
@@ -795,6 +803,23 @@ static uint32_t route_margin_half(uint32_t probes) {
     return std::max<uint32_t>(32, probes / 6);
 }
 
+// CUDDLE_RABITQ_GROUPED = 0 / 1 forces the choice (A/B runs, tests); 2 = grouped with every bound checked against the
+// per-query kernel's own (the search fails if one differs).
+static int rq_grouped_env() {
+    const char *e = getenv("CUDDLE_RABITQ_GROUPED"); // (read at every call: a test sets it for one search)
+    return e ? atoi(e) : -1;
+}
+static bool rq_grouped_wanted(uint32_t nq, uint32_t dim, uint32_t lstride) {
+    const int e = rq_grouped_env();
+    if (e >= 0) return e != 0;
+    // Off unless asked for. Measured on 10M x 768-d, 4096 queries x 100 leaves (4.2 queries per leaf): the bounds of all
+    // pairs take 1.14 ms leaf by leaf against the 0.86 ms they take inside the per-query kernel - expanding a leaf's
+    // bits is shared by too few queries, and what is left per pair (turning the integer into two bounds) costs as much
+    // as the popcounts did. It pays where many queries share a leaf (small indexes, large batches).
+    (void)nq;
+    return false;
+}
+
 // Lays the per-chunk arrays of `pl` (strides and qc already set) out from `b`; returns the bytes they take.
 // b == null: sizing only.
 static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
@@ -821,7 +846,16 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     size_t o_lfc = carve(qc * ((size_t)ix->n_levels + 1) * 4);
     size_t o_ltb = carve(qc * 4 * ((size_t)pl.lstride + 4) * 4);
     size_t o_sg0 = carve(qc * seg_stride(pl.probes) * 4), o_sg1 = carve(qc * seg_stride(pl.probes) * 4);
-    size_t o_rqr = carve(v.code_kind == CUDDLE_CODE_RABITQ ? qc * (size_t)rq_plane_stride(v.words32) * 4 : 0);
+    const bool rq = v.code_kind == CUDDLE_CODE_RABITQ;
+    size_t o_rqr = carve(rq ? qc * (size_t)rq_plane_stride(v.words32) * 4 : 0);
+    // the grouped bounds: sized for every (query, leaf-list slot) pair and every node (pl.rq_grouped decides their use)
+    const bool rg = rq && pl.rq_grouped;
+    const size_t npair = rg ? qc * pl.lstride : 0, nnode = rg ? (size_t)v.n_nodes + 1 : 0;
+    size_t o_ri8 = carve(rg ? qc * (size_t)rq_i8_stride(v.dim) : 0);
+    size_t o_rpi = carve(npair * 8), o_rpn = carve(npair * 4), o_rps = carve(npair * 4), o_rpo = carve(npair * 8);
+    size_t o_rc = carve(nnode * 4), o_rpf = carve(nnode * 4), o_rio = carve(nnode * 4);
+    size_t o_rbs = carve(rg ? 2 * ((nnode + kPairScanChunk - 1) / kPairScanChunk + 1) * 4 : 0);
+    size_t o_rit = carve(rg ? (npair / kGroupPairs + nnode + 1) * 16 : 0);
     if (!b) return off;
     pl.qcodes = (uint64_t *)(b + o_qcodes);
     pl.frontier[0] = (uint32_t *)(b + o_f0); pl.frontier[1] = (uint32_t *)(b + o_f1);
@@ -846,6 +880,11 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     pl.leaf_tables = (uint32_t *)(b + o_ltb);
     pl.seg[0] = (uint32_t *)(b + o_sg0); pl.seg[1] = (uint32_t *)(b + o_sg1);
     pl.rq_rows = (uint32_t *)(b + o_rqr);
+    pl.rq_i8 = (int8_t *)(b + o_ri8);
+    pl.rq_pinfo = (uint32_t *)(b + o_rpi); pl.rq_pnode = (uint32_t *)(b + o_rpn); pl.rq_pslot = (uint32_t *)(b + o_rps);
+    pl.rq_psorted = (uint32_t *)(b + o_rpo);
+    pl.rq_cnt = (uint32_t *)(b + o_rc); pl.rq_poff = (uint32_t *)(b + o_rpf); pl.rq_ioff = (uint32_t *)(b + o_rio);
+    pl.rq_bsum = (uint32_t *)(b + o_rbs); pl.rq_items = (uint32_t *)(b + o_rit);
     return off;
 }
 
@@ -920,6 +959,9 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
         pl.scan_lds = rabitq_scan_lds_bytes(v.dim, pl.lstride, pl.tcap, pl.dist_cap);
     }
     if (pl.scan_lds > 150 * 1024) return fail(CUDDLE_ERR_UNSUPPORTED, "leaf list of %u slots does not fit the scan kernel's LDS", pl.lstride);
+    // RaBitQ bounds leaf by leaf on the matrix cores: pays once a leaf is shared by several queries of the chunk, i.e. for
+    // batches (the per-query kernel computes its own bounds otherwise); dimensions the kernel has an instantiation for
+    pl.rq_grouped = v.code_kind == CUDDLE_CODE_RABITQ && rq_grouped_wanted(nq, v.dim, pl.lstride);
     pl.kc_split = (uint32_t)align_up((size_t)pl.probes + route_margin(pl.probes), 4); // every candidate costs an exact distance
     pl.kc_half = (uint32_t)align_up((size_t)pl.probes + route_margin_half(pl.probes), 4);
     pl.kc_cap = std::max(pl.kc_split, pl.kc_half);
@@ -1013,7 +1055,8 @@ static cuddle_status launch_quantize(cuddle_index *ix, const Plan &pl, const flo
         float *rq = reinterpret_cast<float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
         hipLaunchKernelGGL(rabitq_query_prep_kernel, dim3((nq + kPrepQ - 1) / kPrepQ), dim3(std::min(1024u, (v.dim + 63) & ~63u)), kPrepQ * v.dim * sizeof(float),
                            s, dq, v.rot, nq, v.dim, rq, qn);
-        hipLaunchKernelGGL(rabitq_query_planes_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, rq, qn, nq, v.dim, v.words32, pl.rq_rows);
+        hipLaunchKernelGGL(rabitq_query_planes_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, rq, qn, nq, v.dim, v.words32, pl.rq_rows,
+                           pl.rq_grouped ? pl.rq_i8 : (int8_t *)nullptr);
     }
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
@@ -1351,10 +1394,43 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
     if (v.code_kind == CUDDLE_CODE_RABITQ) {
         static const bool rabitq_exact_all = getenv("CUDDLE_RABITQ_EXACT_ALL") != nullptr; // A/B aid: no bounds, every estimate exact
         const float *rq = reinterpret_cast<const float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
+        uint32_t pre_bounds = 0;
+        if (pl.rq_grouped && !rabitq_exact_all) {
+            // the (query, leaf) pairs of the leaf lists in leaf order, cut into work items; then the bounds of every
+            // pair's candidates on the matrix cores, written to the queries' spill rows
+            const uint32_t n = v.n_nodes, total = nq * pl.lstride, nb = (n + kPairScanChunk - 1) / kPairScanChunk;
+            HIP_TRY(hipMemsetAsync(pl.rq_cnt, 0, ((size_t)n + 1) * 4, s));
+            hipLaunchKernelGGL(rq_pairs_kernel, dim3((pl.lstride + 255) / 256, nq), dim3(256), 0, s, pl.leaf_tables, tstride, pl.leaves,
+                               pl.lstride, pl.rq_cnt, reinterpret_cast<uint2 *>(pl.rq_pinfo), pl.rq_pnode, pl.rq_pslot);
+            const bool self_carry = nb <= 16;
+            if (!self_carry) {
+                hipLaunchKernelGGL(pair_block_sums_kernel, dim3(nb), dim3(256), 0, s, pl.rq_cnt, n, pl.rq_bsum, nb);
+                hipLaunchKernelGGL(pair_block_scan_kernel, dim3(1), dim3(1024), 0, s, pl.rq_bsum, nb, n, pl.rq_poff, pl.rq_ioff);
+            }
+            hipLaunchKernelGGL(pair_scan_kernel, dim3(nb), dim3(256), 0, s, pl.rq_cnt, n, self_carry ? nullptr : pl.rq_bsum, nb, pl.rq_poff,
+                               pl.rq_ioff, reinterpret_cast<uint4 *>(pl.rq_items), (const uint2 *)nullptr);
+            hipLaunchKernelGGL(rq_pair_fill_kernel, dim3((total + 255) / 256), dim3(256), 0, s, reinterpret_cast<const uint2 *>(pl.rq_pinfo),
+                               pl.rq_pnode, pl.rq_pslot, total, pl.rq_poff, reinterpret_cast<uint2 *>(pl.rq_psorted));
+            const uint32_t max_items = total / kGroupPairs + std::min(n, total) + 1;
+            static const int mt = getenv("CUDDLE_RQ_MT") ? atoi(getenv("CUDDLE_RQ_MT")) : 8; // tuning aid: 16-vector tiles per pass
+#define CUDDLE_RQ_GROUPED(MT)                                                                                                 \
+    hipLaunchKernelGGL(rq_bounds_grouped_kernel<MT>, dim3((max_items + 3) / 4), dim3(256), 0, s, v, pl.rq_ioff + n,              \
+                       reinterpret_cast<const uint4 *>(pl.rq_items), reinterpret_cast<const uint2 *>(pl.rq_psorted), pl.rq_i8,  \
+                       pl.rq_rows, qn, reinterpret_cast<float *>(pl.gdist), pl.cstride)
+            if (mt == 4) CUDDLE_RQ_GROUPED(4); else if (mt == 2) CUDDLE_RQ_GROUPED(2); else CUDDLE_RQ_GROUPED(8);
+#undef CUDDLE_RQ_GROUPED
+            pre_bounds = rq_grouped_env() == 2 ? 2u : 1u;
+        }
         hipLaunchKernelGGL(scan_select_rabitq_kernel, dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, rq, qn, pl.leaf_tables,
                            tstride, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, reinterpret_cast<float *>(pl.gdist),
                            pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, rabitq_exact_all ? 1u : 0u,
-                           &ix->d_stats->rq_exact, pl.rq_rows);
+                           &ix->d_stats->rq_exact, pl.rq_rows, pre_bounds);
+        if (pre_bounds == 2) { // checking mode: any bound that differs from the per-query kernel's fails the search
+            DevStats h;
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipMemcpy(&h, ix->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+            if (h.rq_mismatch) return fail(CUDDLE_ERR_HIP, "%llu RaBitQ bounds of the grouped kernel differ from the per-query kernel's", h.rq_mismatch);
+        }
         hipLaunchKernelGGL(selection_sort_f32_kernel, dim3(nq), dim3(256), (size_t)host_next_pow2(pl.sstride) * 8, s,
                            pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.sel_ord);
         HIP_TRY(hipGetLastError());

@@ -245,14 +245,17 @@ __device__ __forceinline__ float rabitq_estimate_from_ip(float ip, float qnorm, 
 // per batch by rabitq_query_planes_kernel and read by the scan through scalar loads (the row is the same for every
 // lane, so its words sit in scalar registers and cost the vector unit nothing):
 //   [0] delta (f32)  [1] a_q (f32)  [2] b_q (f32)   (E_c = norm_c * (a_q + b_q / ip_oo_c))   [3] sum of the quantised values
+//   [4] sum of the quantised values with the signs of rq (i32)
 //   [8 + 12 w + 0] sign bits of rq (dimensions 32 w .. 32 w + 31)   [8 + 12 w + 1 + p] bit plane p of the quantised magnitudes
 constexpr uint32_t kRqWordStride = (kRqPlanes + 1 + 3) & ~3u; // sign word + planes, padded to whole 16-byte pieces
 __host__ __device__ inline uint32_t rq_plane_stride(uint32_t words32) { return 8 + kRqWordStride * words32; }
 
 // Quantises |rq| of every query to kRqPlanes bits and writes its row (layout above). One wave per query.
+// pieces != null: also the signed quantised values as two 5-bit pieces, [nq][2][dim rounded up to 64] i8
+// (value = 32 * pieces[1] + pieces[0], zero past dim), the operand of rq_bounds_grouped_kernel.
 __global__ void __launch_bounds__(256)
 rabitq_query_planes_kernel(const float *rq_all, const float *qnorm_all, uint32_t nq, uint32_t dim, uint32_t words32,
-                           uint32_t *rows) {
+                           uint32_t *rows, int8_t *pieces) {
     const uint32_t lane = threadIdx.x & 63, q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (q >= nq) return;
     const float *rq = rq_all + (uint64_t)q * dim;
@@ -268,6 +271,8 @@ rabitq_query_planes_kernel(const float *rq_all, const float *qnorm_all, uint32_t
     const float delta = mx / (float)VMAX, inv = mx > 0.f ? (float)VMAX / mx : 0.f;
     float res = 0.f, asum = 0.f;
     uint32_t vsum = 0;
+    int ssum = 0;
+    static_assert(kRqPlanes <= 10, "the signed pieces hold 5 bits each");
     for (uint32_t i = lane; i < dpad; i += 64) {
         const uint32_t bits = (i < dim && live) ? __float_as_uint(rq[i]) : 0u;
         const float a = __uint_as_float(bits & 0x7FFFFFFFu);
@@ -276,6 +281,13 @@ rabitq_query_planes_kernel(const float *rq_all, const float *qnorm_all, uint32_t
         res += fabsf(a - delta * (float)v);
         asum += a;
         vsum += v;
+        const int sv = (bits >> 31) ? -(int)v : (int)v;
+        ssum += sv;
+        if (pieces) {
+            int8_t *pc = pieces + (uint64_t)q * 2 * dpad;
+            pc[i] = (int8_t)((bits >> 31) ? -(int)(v & 31u) : (int)(v & 31u));
+            pc[dpad + i] = (int8_t)((bits >> 31) ? -(int)(v >> 5) : (int)(v >> 5));
+        }
         const uint64_t sb = __ballot((bits >> 31) != 0);
         uint32_t *w0 = row + 8 + (size_t)kRqWordStride * (i >> 5); // i is a multiple of 64 in lane 0
         const bool second = (i >> 5) + 1 < words32;
@@ -297,8 +309,10 @@ rabitq_query_planes_kernel(const float *rq_all, const float *qnorm_all, uint32_t
         res += __shfl_xor(res, o, 64);
         asum += __shfl_xor(asum, o, 64);
         vsum += __shfl_xor(vsum, o, 64);
+        ssum += __shfl_xor(ssum, o, 64);
     }
     if (lane == 0) {
+        row[4] = (uint32_t)ssum;
         // |ip~ - ip| <= B: quantisation residue (computed in f32: 0.2 % slack) + the rounding of the reference's
         // sequential f32 sum and of delta * integer (each below dim * 2^-23 times the sum of magnitudes)
         const float B = 1.002f * res + ((float)dim + 8.0f) * 1.2e-7f * (asum + res);
@@ -309,6 +323,25 @@ rabitq_query_planes_kernel(const float *rq_all, const float *qnorm_all, uint32_t
         row[2] = __float_as_uint(1.001f * qnorm * (2.0f * B + 1e-5f * (asum + B)));
         row[3] = vsum;
     }
+}
+
+// Upper (returned) and lower bound of the estimate from the integer S = sum_i (+-1) sgn(rq_i) v_i; both rounded
+// outwards. The one formula of the per-query and the leaf-by-leaf kernel (their bounds agree bit for bit).
+// 1 / ip_oo is the hardware's reciprocal (1 ulp): against the reference's division the quotient moves by under
+// 3e-7 of itself, the estimate by under 1e-6 norm qnorm - inside the 1e-5 norm qnorm that a_q sets aside for the
+// roundings of either evaluation - and b_q / ip_oo by a relative 3e-7, inside the 0.1 % slack of b_q.
+__device__ __forceinline__ float rabitq_bounds_from_sum(int S, float delta, float aq, float bq, float qnorm, float norm, float ipoo,
+                                                        float &lb) {
+    if (norm < 1e-10f) { // exact (rabitq.rs:342-349)
+        lb = qnorm * qnorm;
+        return lb;
+    }
+    const float inv = __builtin_amdgcn_rcpf(ipoo);
+    const float ip = delta * (float)S;
+    const float est = (2.0f - 2.0f * (ip * inv)) * norm * qnorm;
+    const float E = norm * (aq + bq * inv), round_out = 1e-6f * fabsf(est) + 1e-6f * E;
+    lb = est - E - round_out;
+    return est + E + round_out;
 }
 
 // popcount(x) + acc in one instruction (the compiler otherwise splits it into a count and a three-way add).
@@ -350,12 +383,8 @@ __device__ __forceinline__ float rabitq_bounds(const uint32_t *__restrict__ code
     uint32_t K = 0;
 #pragma unroll
     for (uint32_t p = 0; p < kRqPlanes; ++p) K += cnt[p] << p;
-    const float delta = __uint_as_float(row[0]), aq = __uint_as_float(row[1]), bq = __uint_as_float(row[2]);
-    const float ip = delta * (float)((int)row[3] - 2 * (int)K);
-    const float est = (2.0f - 2.0f * (ip / ipoo)) * norm * qnorm;
-    const float E = norm * (aq + bq / ipoo), round_out = 1e-6f * fabsf(est) + 1e-6f * E;
-    lb = est - E - round_out;
-    return est + E + round_out;
+    return rabitq_bounds_from_sum((int)row[3] - 2 * (int)K, __uint_as_float(row[0]), __uint_as_float(row[1]), __uint_as_float(row[2]),
+                                  qnorm, norm, ipoo, lb);
 }
 
 // compute_inner_product_fast for two vectors (see rabitq_ip_pair) whose codes are read from the vector-major copy:
@@ -411,7 +440,7 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
                           uint32_t tstride, uint32_t lcap, uint32_t tcap, uint32_t rerank_k,
                           uint32_t dist_cap, float *gest, uint32_t gest_stride, uint32_t *sel_pos, uint32_t *sel_key,
                           uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count, uint32_t exact_all,
-                          unsigned long long *stats, const uint32_t *__restrict__ qrows) {
+                          unsigned long long *stats, const uint32_t *__restrict__ qrows, uint32_t pre_bounds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const uint32_t D = ix.dim, W32 = ix.words32;
@@ -440,9 +469,15 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
     CUDDLE_STAMP(6, 1);
     if (filtered) {
         if (tid == 0) isc[1] = 0; // members
+        if (pre_bounds) {
+            // rq_bounds_grouped_kernel has left the bounds in the query's spill row: the upper bounds move to where the
+            // selection reads them (pre_bounds == 2, a debugging aid: they are recomputed below and compared instead)
+            if (use_lds && pre_bounds == 1)
+                for (uint32_t i = tid; i < C; i += blockDim.x) r.est[i] = ge[i];
+        }
         // this query's row of quantised magnitudes: a wave-uniform address, so its words are read into scalar registers
         const uint32_t *row = qrows + (uint64_t)__builtin_amdgcn_readfirstlane(q) * rq_plane_stride(W32);
-        for (uint32_t t = w; t < ntiles; t += nw) {
+        for (uint32_t t = w; t < ntiles && pre_bounds != 1; t += nw) {
             // one tile = 64 consecutive vectors of one leaf: everything but the lane's own vector is the same for the wave
             const uint32_t tile = __builtin_amdgcn_readfirstlane(s.tiles[t]), sl = tile >> 12, i = ((tile & 4095u) << 6) + lane;
             const uint32_t base = __builtin_amdgcn_readfirstlane(s.lscan[sl]);
@@ -451,8 +486,11 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
             if (i < n) {
                 const uint32_t pos = beg + i;
                 float lb;
-                est_put(base + i, rabitq_bounds(ix.rq_codes + (uint64_t)beg * W32, n, i, W32, row, qnorm, ix.rq_norm[pos],
-                                                ix.rq_ipoo[pos], lb));
+                const float ub = rabitq_bounds(ix.rq_codes + (uint64_t)beg * W32, n, i, W32, row, qnorm, ix.rq_norm[pos], ix.rq_ipoo[pos], lb);
+                if (pre_bounds == 2 && stats &&
+                    (__float_as_uint(ub) != __float_as_uint(ge[base + i]) || __float_as_uint(lb) != __float_as_uint(glb[base + i])))
+                    atomicAdd(&stats[2], 1ull);
+                est_put(base + i, ub);
                 glb[base + i] = lb;
             }
         }
