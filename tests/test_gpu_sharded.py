@@ -226,3 +226,23 @@ def test_sharded_batch_larger_than_one_round(gpu):
     torch.cuda.synchronize()
     assert ids1.shape[0] == 4300 and torch.equal(ids0, ids1) and torch.equal(c0, c1)
     assert np.array_equal(_bits(d0.cpu().numpy()), _bits(d1.cpu().numpy()))
+
+
+def test_sharded_rabitq_many_leaves_and_a_selection_near_the_cap(gpu):
+    """probes >= 1000 and a selection close to 10 000: every member's leaf slot (part of its exchange key) is found
+    among well over a thousand leaf slots; the keys must still order candidates as the unsharded selection does."""
+    rng = np.random.default_rng(11)
+    n, d, nl = 48000, 32, 1600
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    from vectordb_amd import _ffi
+    from vectordb_amd.builder import make_rotation, rabitq_encode
+    from vectordb_amd.flat_index import FlatIndex
+    rot = make_rotation(d, 5)
+    codes, norms, ipoo = rabitq_encode(torch.from_numpy(x), torch.from_numpy(rot))
+    cent = x.reshape(nl, n // nl, d).mean(axis=1)
+    fi = FlatIndex(dim=d, metric=_ffi.METRIC_L2, code_kind=_ffi.CODE_RABITQ, centroids=cent, child_offsets=np.zeros(nl + 1, np.uint32),
+                   children=np.zeros(0, np.uint32), roots=np.arange(nl, dtype=np.uint32),
+                   vec_offsets=(np.arange(nl + 1) * (n // nl)).astype(np.uint64), ids=np.arange(n, dtype=np.uint64), vectors=x,
+                   rabitq_rot_t=rot, rabitq_codes=np.asarray(codes), rabitq_norm=np.asarray(norms), rabitq_ip_oo=np.asarray(ipoo))
+    q = x[rng.integers(0, n, 12)] + 0.05 * rng.standard_normal((12, d)).astype(np.float32)
+    _check(fi, gpu, q, [(100, 1200, 95)], worlds=(3,))

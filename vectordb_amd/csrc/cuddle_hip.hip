@@ -2425,7 +2425,7 @@ static cuddle_status shard_scan_impl(cuddle_index *idx, const float *d_queries, 
     if (d_keys) {
         if (pl.lstride >= (1u << kRqSlotBits)) return fail(CUDDLE_ERR_UNSUPPORTED, "leaf lists of %u slots: the key holds %u bits", pl.lstride, kRqSlotBits);
         ST_TRY(launch_scan_select(idx, pl, n_queries, s));
-        hipLaunchKernelGGL(rq_exchange_keys_kernel, dim3(n_queries), dim3(256), (size_t)2 * pl.lstride * 4, s, idx->dev, pl.leaves, pl.lstride,
+        hipLaunchKernelGGL(rq_exchange_keys_kernel, dim3(n_queries), dim3(256), rq_exchange_lds_bytes(pl.lstride), s, idx->dev, pl.leaves, pl.lstride,
                            pl.lcount, pl.lstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.rerank_k, d_keys, pl.sel_ord);
         HIP_TRY(hipGetLastError());
     } else {

@@ -272,7 +272,7 @@ rabitq_query_planes_kernel(const float *rq_all, const float *qnorm_all, uint32_t
     float res = 0.f, asum = 0.f;
     uint32_t vsum = 0;
     int ssum = 0;
-    static_assert(kRqPlanes <= 10, "the signed pieces hold 5 bits each");
+    static_assert(kRqPlanes <= 12, "the signed pieces are bytes: low 5 bits, the rest (at most 7 bits)");
     for (uint32_t i = lane; i < dpad; i += 64) {
         const uint32_t bits = (i < dim && live) ? __float_as_uint(rq[i]) : 0u;
         const float a = __uint_as_float(bits & 0x7FFFFFFFu);

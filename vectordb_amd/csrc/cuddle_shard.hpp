@@ -224,30 +224,47 @@ merge_ordered_kernel(const uint64_t *ids, const float *dist, const uint64_t *ord
 
 // keys[q][i] (i < rerank_k; ~0 past the rank's selection) and sel_ord[q][i] = the exchange key of the i-th
 // entry of the rank's sorted phase-1 selection. The leaf slot of an entry is found from its position:
-// the query's leaves own disjoint position ranges (leaves of other ranks are empty here).
-// One block per query; dynamic LDS = 2 * lcap * 4 bytes.
+// the query's leaves own disjoint position ranges (leaves of other ranks are empty here), so the slots'
+// first positions are sorted once per query and every entry's slot is a binary search away.
+// One block per query; dynamic LDS = rq_exchange_lds_bytes(lcap).
+inline size_t rq_exchange_lds_bytes(uint32_t lcap) {
+    uint32_t npad = 1;
+    while (npad < lcap) npad <<= 1;
+    return (size_t)npad * 8;
+}
+
 __global__ void __launch_bounds__(256)
 rq_exchange_keys_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const uint32_t *lcount, uint32_t lcap,
                         const uint32_t *sel_pos, const uint32_t *sel_key, uint32_t sel_stride, const uint32_t *sel_count,
                         uint32_t rerank_k, uint64_t *keys, uint64_t *sel_ord) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *lb = reinterpret_cast<uint32_t *>(smem), *le = lb + lcap;
+    uint64_t *first = reinterpret_cast<uint64_t *>(smem); // [npad] (first position << 32 | slot) of the non-empty slots, ascending
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t nl = min(lcount[q], lcap), n = min(min(sel_count[q], sel_stride), rerank_k);
-    for (uint32_t sl = tid; sl < nl; sl += blockDim.x) {
-        const uint32_t node = leaves[(uint64_t)q * lstride + sl];
-        lb[sl] = (uint32_t)ix.vec_off[node];
-        le[sl] = (uint32_t)ix.vec_off[node + 1];
+    const uint32_t npad = next_pow2(max(lcap, 1u));
+    for (uint32_t sl = tid; sl < npad; sl += blockDim.x) {
+        uint64_t e = ~0ull;
+        if (sl < nl) {
+            const uint32_t node = leaves[(uint64_t)q * lstride + sl];
+            const uint32_t b = (uint32_t)ix.vec_off[node], en = (uint32_t)ix.vec_off[node + 1];
+            if (en > b) e = ((uint64_t)b << 32) | sl;
+        }
+        first[sl] = e;
     }
     __syncthreads();
+    block_bitonic_sort_u64(first, npad);
     for (uint32_t i = tid; i < rerank_k; i += blockDim.x) {
         uint64_t key = ~0ull;
         if (i < n) {
             const uint32_t pos = sel_pos[(uint64_t)q * sel_stride + i];
-            uint32_t sl = 0;
-            while (sl + 1 < nl && !(pos >= lb[sl] && pos < le[sl])) ++sl;
+            uint32_t lo = 0, hi = npad; // the last entry whose first position is <= pos (a selected position lies in a non-empty slot)
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((uint32_t)(first[mid] >> 32) <= pos) lo = mid; else hi = mid;
+            }
+            const uint64_t e = first[lo];
             key = ((uint64_t)f32_key(__uint_as_float(sel_key[(uint64_t)q * sel_stride + i])) << 32) |
-                  ((uint64_t)sl << kRqLeafPosBits) | (pos - lb[sl]);
+                  ((uint64_t)(uint32_t)e << kRqLeafPosBits) | (pos - (uint32_t)(e >> 32));
             sel_ord[(uint64_t)q * sel_stride + i] = key;
         }
         keys[(uint64_t)q * rerank_k + i] = key;
