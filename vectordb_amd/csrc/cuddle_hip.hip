@@ -236,8 +236,6 @@ struct Plan {
     float *qinv = nullptr;     // inverse scale of every query's half-precision row
     uint16_t *qcent = nullptr; // centred queries as bf16 (hi, lo) pairs, or as scaled fp16
     uint32_t *rc_pos = nullptr, *rflag = nullptr, *rc_cnt = nullptr;
-    // refinement node by node (route_refine_node_kernel): the candidates' places among their node's, the pairs in node order
-    uint32_t *rc_place = nullptr, *rn_cnt = nullptr, *rn_poff = nullptr, *rn_ioff = nullptr, *rn_items = nullptr, *rn_sorted = nullptr;
     size_t bytes = 0;
 };
 
@@ -326,7 +324,6 @@ static uint64_t grouped_half_min_bytes() {
 }
 
 static constexpr uint32_t kGemmMinWidth = 512; // narrower levels are routed by the exact kernel
-static constexpr uint32_t kRefineNodeMaxWidth = 16384; // widest shared level refined node by node (16 chunks of the pair scan)
 static constexpr uint32_t kMaxLeafVectors = 4096u * 64u; // the scan's tile tables hold the tile number inside a leaf in 12 bits
 static constexpr uint32_t kMaxCandidates = 1u << 25;    // ... and a tile's scan position in 25 bits
 static constexpr uint32_t kLdsDistCap = 24576; // u16 distances kept in LDS per query (48 KiB)
@@ -756,7 +753,6 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     // a query vector in LDS: more than 64 KiB from 16 385 dimensions on
     (void)hipFuncSetAttribute((const void *)rerank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)route_refine_node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_dist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // the leaf tables of the sharded selection steps: 16 bytes per leaf slot
     (void)hipFuncSetAttribute((const void *)shard_ties_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -850,9 +846,6 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     size_t o_lfc = carve(qc * ((size_t)ix->n_levels + 1) * 4);
     size_t o_ltb = carve(qc * 4 * ((size_t)pl.lstride + 4) * 4);
     size_t o_sg0 = carve(qc * seg_stride(pl.probes) * 4), o_sg1 = carve(qc * seg_stride(pl.probes) * 4);
-    const size_t rn_w = kRefineNodeMaxWidth + 1;
-    size_t o_rnp = carve(qc * pl.kc_cap * 4), o_rnc = carve(rn_w * 4), o_rno = carve(rn_w * 4), o_rni = carve(rn_w * 4);
-    size_t o_rnt = carve((qc * pl.kc_cap / kGroupPairs + rn_w + 1) * 16), o_rns = carve(qc * pl.kc_cap * 4);
     const bool rq = v.code_kind == CUDDLE_CODE_RABITQ;
     size_t o_rqr = carve(rq ? qc * (size_t)rq_plane_stride(v.words32) * 4 : 0);
     // the grouped bounds: sized for every (query, leaf-list slot) pair and every node (pl.rq_grouped decides their use)
@@ -886,8 +879,6 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     pl.level_fc = (uint32_t *)(b + o_lfc);
     pl.leaf_tables = (uint32_t *)(b + o_ltb);
     pl.seg[0] = (uint32_t *)(b + o_sg0); pl.seg[1] = (uint32_t *)(b + o_sg1);
-    pl.rc_place = (uint32_t *)(b + o_rnp); pl.rn_cnt = (uint32_t *)(b + o_rnc); pl.rn_poff = (uint32_t *)(b + o_rno);
-    pl.rn_ioff = (uint32_t *)(b + o_rni); pl.rn_items = (uint32_t *)(b + o_rnt); pl.rn_sorted = (uint32_t *)(b + o_rns);
     pl.rq_rows = (uint32_t *)(b + o_rqr);
     pl.rq_i8 = (int8_t *)(b + o_ri8);
     pl.rq_pinfo = (uint32_t *)(b + o_rpi); pl.rq_pnode = (uint32_t *)(b + o_rpn); pl.rq_pslot = (uint32_t *)(b + o_rps);
@@ -1081,10 +1072,10 @@ static void launch_query_norms(cuddle_index *ix, const Plan &pl, const float *dq
 // on the frontier width allows (unused key slots still cost their predicated instructions in every pass).
 // ncount / skip / cand_cnt: per-query frontiers (see route_prefilter_reg_kernel).
 static void launch_prefilter(const Plan &pl, uint32_t nq, uint32_t n, uint32_t kc, const uint32_t *ncount, const uint32_t *skip,
-                             uint32_t *cand_cnt, hipStream_t s, uint32_t *node_cnt = nullptr) {
+                             uint32_t *cand_cnt, hipStream_t s) {
 #define CUDDLE_PREFILTER(T, K)                                                                                                \
     hipLaunchKernelGGL((route_prefilter_reg_kernel<T, K>), dim3(nq), dim3(T), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,    \
-                       pl.kc_cap, pl.rc_max, ncount, skip, cand_cnt, node_cnt, pl.rc_place)
+                       pl.kc_cap, pl.rc_max, ncount, skip, cand_cnt)
     if (n <= 128 * 8) CUDDLE_PREFILTER(128, 8);
     else if (n <= 256 * 8) CUDDLE_PREFILTER(256, 8);
     else if (n <= 256 * 16) CUDDLE_PREFILTER(256, 16);
@@ -1314,30 +1305,13 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             used_half |= half;
             const uint32_t n = g.n, kc = std::min(n, half ? pl.kc_half : pl.kc_split);
             launch_level_gemm(ix, pl, g, dq, nq, s, half);
-            // node by node where a node is shortlisted by many queries: its centroid is then read once instead of once per query
-            static const int node_env = getenv("CUDDLE_REFINE_BY_NODE") ? atoi(getenv("CUDDLE_REFINE_BY_NODE")) : -1; // tuning aid
-            const bool by_node = n <= kRefineNodeMaxWidth && kc < 65536 && nq <= 65536 &&
-                                 (node_env >= 0 ? node_env != 0 : (uint64_t)nq * kc >= 8ull * n);
-            if (by_node) HIP_TRY(hipMemsetAsync(pl.rn_cnt, 0, ((size_t)n + 1) * 4, s));
             if (n <= 512 * 32)
-                launch_prefilter(pl, nq, n, kc, nullptr, nullptr, nullptr, s, by_node ? pl.rn_cnt : nullptr);
+                launch_prefilter(pl, nq, n, kc, nullptr, nullptr, nullptr, s);
             else
                 hipLaunchKernelGGL(route_prefilter_kernel, dim3(nq), dim3(256), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,
                                    pl.kc_cap, pl.rc_max);
-            if (by_node) {
-                const uint32_t nb = (n + kPairScanChunk - 1) / kPairScanChunk; // <= 16: the scan carries the chunks before its own itself
-                hipLaunchKernelGGL(pair_scan_kernel, dim3(nb), dim3(256), 0, s, pl.rn_cnt, n, (const uint32_t *)nullptr, nb, pl.rn_poff,
-                                   pl.rn_ioff, reinterpret_cast<uint4 *>(pl.rn_items), (const uint2 *)nullptr);
-                hipLaunchKernelGGL(refine_fill_kernel, dim3((kc + 255) / 256, nq), dim3(256), 0, s, pl.rc_pos, pl.rc_place, pl.kc_cap, kc, nq,
-                                   pl.rn_poff, pl.rn_sorted);
-                const uint32_t max_items = nq * kc / kGroupPairs + std::min<uint32_t>(n, nq * kc) + 1;
-                hipLaunchKernelGGL(route_refine_node_kernel, dim3(max_items), dim3(128), (((size_t)v.dim + 3) & ~(size_t)3) * sizeof(float), s, v,
-                                   dq, g.nodes, pl.rn_ioff + n, reinterpret_cast<const uint4 *>(pl.rn_items), pl.rn_sorted, pl.kc_cap,
-                                   pl.rc_dist, pl.qnorm);
-            } else {
             hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                g.nodes, pl.rc_pos, pl.kc_cap, kc, pl.rc_dist, pl.qnorm);
-            }
             hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(kc), pl.probes), s,
                                v, g.nodes, n, pl.rc_pos, pl.rc_dist, pl.kc_cap, kc, pl.rc_max, pl.qsq, g.max_sqn, pl.probes,
                                pl.frontier[cur ^ 1], pl.fstride, pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,

@@ -1662,14 +1662,11 @@ route_prefilter_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_
 // kept is free: every unselected node still has d~ >= cand_max, which is all the proof needs).
 // ncount != null: per-query frontiers of ncount[q] nodes (at most n); queries with skip[q] != 0 are
 // left alone; cand_cnt[q] = the query's number of candidates, min(kc, ncount[q]).
-// node_cnt != null (a level every query sees whole): every winner also takes a place among the candidates of its
-// node, node_cnt[level position]++ -> cand_place[q][slot], for the refinement that goes node by node.
 template <int THREADS, int KPT>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KPT <= 20 ? 8 : 4)))
 route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uint32_t kc, uint32_t *cand_pos,
                            uint32_t cstride, float *cand_max, const uint32_t *ncount = nullptr,
-                           const uint32_t *skip = nullptr, uint32_t *cand_cnt = nullptr, uint32_t *node_cnt = nullptr,
-                           uint32_t *cand_place = nullptr) {
+                           const uint32_t *skip = nullptr, uint32_t *cand_cnt = nullptr) {
     __shared__ uint32_t hist[4 * 256];
     __shared__ uint32_t misc[4];
     __shared__ uint32_t wred[2 * (THREADS / 64)];
@@ -1741,16 +1738,12 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
     for (int t = 0; t < KPT; ++t) {
         const uint32_t i = t * THREADS + tid;
         if (i < n) {
-            uint32_t slot = 0xFFFFFFFFu;
             if (keys[t] < T) {
-                slot = atomicAdd(&misc[2], 1u);
+                const uint32_t slot = atomicAdd(&misc[2], 1u);
+                if (slot < cstride) cp[slot] = i;
             } else if (keys[t] == T) {
                 const uint32_t ts = atomicAdd(&misc[3], 1u);
-                if (ts < budget) slot = n_lt + ts;
-            }
-            if (slot < cstride) {
-                cp[slot] = i;
-                if (node_cnt) cand_place[(uint64_t)q * cstride + slot] = atomicAdd(&node_cnt[i], 1u);
+                if (ts < budget && n_lt + ts < cstride) cp[n_lt + ts] = i;
             }
         }
     }
@@ -1790,39 +1783,6 @@ route_refine_kernel(IndexDev ix, const float *queries, const uint32_t *level_nod
     float d = distance_group4_qn(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, (D & 3) == 0,
                                  ix.metric == kMetricCosine ? qnorm[q] : 0.f);
     if (sub == 0) cand_dist[(uint64_t)q * cstride + j] = d;
-}
-
-// The (query, candidate slot) pairs of a shared level in node order: sorted[poff[node] + place] = q << 16 | slot.
-__global__ void refine_fill_kernel(const uint32_t *cand_pos, const uint32_t *cand_place, uint32_t cstride, uint32_t kc, uint32_t nq,
-                                   const uint32_t *poff, uint32_t *sorted) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
-    if (j >= kc || q >= nq) return;
-    const uint64_t at = (uint64_t)q * cstride + j;
-    sorted[poff[cand_pos[at]] + cand_place[at]] = (q << 16) | j;
-}
-
-// route_refine_kernel turned round for a level every query sees whole: one block per work item (node, up to 64 of
-// the queries that shortlisted it, from pair_scan_kernel). The node's centroid is staged in LDS once and the queries'
-// rows stream past it, a 4-lane group per pair - the same distance() arithmetic with the operands' homes swapped, so
-// every result is the one route_refine_kernel gives. block = 128 (32 pairs per pass); dynamic LDS = pad4(dim) floats.
-__global__ void __launch_bounds__(128)
-route_refine_node_kernel(IndexDev ix, const float *queries, const uint32_t *level_nodes, const uint32_t *n_items, const uint4 *items,
-                         const uint32_t *sorted, uint32_t cstride, float *cand_dist, const float *qnorm) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *cs = reinterpret_cast<float *>(smem);
-    if (blockIdx.x >= *n_items) return;
-    const uint4 it = items[blockIdx.x]; // (level position, first pair, pairs, -)
-    const uint32_t D = ix.dim, node = level_nodes[it.x];
-    const float *cg = ix.centroids + (uint64_t)node * D;
-    for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) cs[i] = cg[i];
-    __syncthreads();
-    const uint32_t sub = threadIdx.x & 3;
-    for (uint32_t p = threadIdx.x >> 2; p < it.z; p += 32) { // (whole 4-lane groups leave together)
-        const uint32_t v = sorted[it.y + p], q = v >> 16, j = v & 0xFFFFu;
-        const float d = distance_group4_qn(queries + (uint64_t)q * D, cs, D, ix.metric, sub, (D & 3) == 0,
-                                           ix.metric == kMetricCosine ? qnorm[q] : 0.f);
-        if (sub == 0) cand_dist[(uint64_t)q * cstride + j] = d;
-    }
 }
 
 inline size_t route_finish_lds_bytes(uint32_t kpad, uint32_t probes) { // keys, expansion scratch, segment table
