@@ -159,9 +159,38 @@ def test_batch_larger_than_one_chunk(gpu):
     assert np.array_equal(ids[sel], ids2) and np.array_equal(dist[sel], dist2)
     orc = _oracle()
     oi = orc.OracleIndex(fi)
-    for i in (0, 4095, 4096, 4999):
+    for i in (0, 2499, 2500, 4095, 4096, 4999):  # (the two pieces of such a batch run on two streams: 0..2499, 2500..4999)
         r = oi.search(q[i], 5, 3, 4)
         assert np.array_equal(ids[i], r["ids"]) and np.array_equal(dist[i], r["dist"])
+    # the statistics of a batch that ran in pieces are those of its parts
+    _, _, _, whole = dev.search_batch(q, 5, 3, 4, want_stats=True)
+    parts = [dev.search_batch(q[a:b], 5, 3, 4, want_stats=True)[3] for a, b in ((0, 3000), (3000, 5000))]
+    for key in ("leaves_searched", "vectors_scanned", "vectors_reranked"):
+        assert whole[key] == parts[0][key] + parts[1][key], key
+    assert whole["max_candidates"] == max(p["max_candidates"] for p in parts)
+
+
+@pytest.mark.parametrize("code_kind", ["binary", "rabitq"])
+def test_four_pieces_on_two_streams(gpu, code_kind):
+    """9000 queries = four pieces of 2250 alternating between the handle's two streams and work-space halves; the
+    device-pointer entry point on a stream of the caller's, twice in a row (the second call must wait for the first's
+    pieces), against single-chunk searches of slices."""
+    import torch
+    x, fi = small_index(n=3000, d=24, n_clusters=20, branching=6, leaf=30, code_kind=code_kind)
+    dev = DeviceIndex(fi, gpu)
+    q = queries_like(x, 9000, 5)
+    dq = torch.from_numpy(q).cuda(gpu)
+    st = torch.cuda.Stream(gpu)
+    st.wait_stream(torch.cuda.current_stream(gpu))
+    a = dev.search_batch_device(dq, 10, 3, 4, stream=st.cuda_stream)
+    b = dev.search_batch_device(dq.flip(0).contiguous(), 10, 3, 4, stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    ids_a, ids_b = a[0].cpu().numpy(), b[0].cpu().numpy()
+    assert np.array_equal(ids_a, ids_b[::-1])
+    for lo in (0, 2200, 4400, 8000):
+        ids, dist, cnt = dev.search_batch(q[lo:lo + 1000], 10, 3, 4)
+        assert np.array_equal(ids.view(np.int64), ids_a[lo:lo + 1000])
+        assert np.array_equal(dist.view(np.uint32), a[1].cpu().numpy()[lo:lo + 1000].view(np.uint32))
 
 
 def test_device_pointer_entry_point_matches_host_one(gpu):
