@@ -224,6 +224,7 @@ struct Plan {
     uint32_t *rq_pinfo = nullptr, *rq_pnode = nullptr, *rq_pslot = nullptr, *rq_psorted = nullptr;
     uint32_t *rq_cnt = nullptr, *rq_poff = nullptr, *rq_ioff = nullptr, *rq_bsum = nullptr, *rq_items = nullptr;
     bool rq_grouped = false;
+    bool leaf_grouped = false; // binary codes: the Hamming scan leaf by leaf (leaf_hamming_kernel), same pair arrays
     uint32_t *level_fc = nullptr; // [n_levels + 1][qc] frontier size of every query at every level (stats variant)
     uint32_t *leaf_tables = nullptr; // [qc][4][lstride + 4] per-slot tables of the reached leaves (cand_count_kernel)
     uint32_t *sel_pos = nullptr, *sel_key = nullptr, *sel_count = nullptr, *cand_count = nullptr;
@@ -363,7 +364,7 @@ static GroupedKernel grouped_kernel_for(uint32_t dim, uint32_t metric) {
 #define CUDDLE_SCAN_U2 8 // tiles a wave keeps in flight when a code is one 16-byte slot (dim <= 128)
 #endif
 using ScanKernel = void (*)(IndexDev, const uint64_t *, const uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
-                            void *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *);
+                            void *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t);
 
 // The Hamming scan instantiation for a code of `words` u64 (distances in u8 when dim < 255).
 static ScanKernel scan_kernel_for(uint32_t dim, uint32_t words) {
@@ -834,6 +835,46 @@ static bool rq_grouped_wanted(uint32_t nq, uint32_t dim, uint32_t lstride) {
     return false;
 }
 
+using LeafKernel8 = void (*)(IndexDev, const uint32_t *, const uint4 *, const uint2 *, const uint64_t *, uint8_t *, uint32_t);
+using LeafKernel16 = void (*)(IndexDev, const uint32_t *, const uint4 *, const uint2 *, const uint64_t *, uint16_t *, uint32_t);
+// The leaf-by-leaf Hamming kernel for a code of `words` u64 (one instantiation per width scan_kernel_for() knows); null otherwise.
+static LeafKernel8 leaf_kernel8_for(uint32_t words) {
+    switch (words) {
+    case 1: return leaf_hamming_kernel<uint8_t, 0, true>;
+    case 2: return leaf_hamming_kernel<uint8_t, 1, false>;
+    case 3: return leaf_hamming_kernel<uint8_t, 1, true>;
+    case 4: return leaf_hamming_kernel<uint8_t, 2, false>;
+    default: return nullptr;
+    }
+}
+static LeafKernel16 leaf_kernel16_for(uint32_t words) {
+    switch (words) {
+    case 4: return leaf_hamming_kernel<uint16_t, 2, false>;
+    case 8: return leaf_hamming_kernel<uint16_t, 4, false>;
+    case 12: return leaf_hamming_kernel<uint16_t, 6, false>;
+    case 15: return leaf_hamming_kernel<uint16_t, 7, true>;
+    case 16: return leaf_hamming_kernel<uint16_t, 8, false>;
+    case 24: return leaf_hamming_kernel<uint16_t, 12, false>;
+    default: return nullptr;
+    }
+}
+
+// Leaf by leaf when the chunk's queries reach a leaf several times over: the leaf's codes are then read once per
+// 64 queries instead of once per query, and the distances cost two bytes per pair to hand over. The number of
+// (query, leaf) pairs is bounded by the leaf-list capacity; a chunk that cannot fill every leaf twice scans per query.
+// CUDDLE_LEAF_GROUPED = 0 / 1 forces the choice (A/B runs, tests).
+static bool leaf_grouped_wanted(const cuddle_index *ix, uint32_t nq, uint32_t lstride) {
+    const IndexDev &v = ix->dev;
+    if (!(v.dim < 255 ? (bool)leaf_kernel8_for(v.words) : (bool)leaf_kernel16_for(v.words))) return false;
+    const char *e = getenv("CUDDLE_LEAF_GROUPED"); // (read at every call: a test sets it for one search)
+    if (e) return atoi(e) != 0;
+    // Measured (step time per query and leaf by leaf): 1000 queries x 232 of 9852 leaves of 960-d codes 0.68 -> 0.51 ms;
+    // 1000 x 200 of 97 336 such leaves 0.92 -> 0.85 ms; 128-d codes lose (2500 x 150 of 9849 leaves 1.39 -> 1.48 ms,
+    // 4096 x 100 of 125 000 leaves 0.56 -> 0.62 ms): a 16-byte code is cheaper to read again than to hand its distance
+    // over, and their searches spend their time selecting, not reading. Codes of 512 bits and more, then.
+    return v.words >= 8 && (uint64_t)nq * lstride >= 2ull * std::max<uint32_t>(ix->n_leaves, 1);
+}
+
 // Lays the per-chunk arrays of `pl` (strides and qc already set) out from `b`; returns the bytes they take.
 // b == null: sizing only.
 static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
@@ -863,9 +904,9 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     const bool rq = v.code_kind == CUDDLE_CODE_RABITQ;
     size_t o_rqr = carve(rq ? qc * (size_t)rq_plane_stride(v.words32) * 4 : 0);
     // the grouped bounds: sized for every (query, leaf-list slot) pair and every node (pl.rq_grouped decides their use)
-    const bool rg = rq && pl.rq_grouped;
+    const bool rg = (rq && pl.rq_grouped) || pl.leaf_grouped;
     const size_t npair = rg ? qc * pl.lstride : 0, nnode = rg ? (size_t)v.n_nodes + 1 : 0;
-    size_t o_ri8 = carve(rg ? qc * (size_t)rq_i8_stride(v.dim) : 0);
+    size_t o_ri8 = carve(rq && pl.rq_grouped ? qc * (size_t)rq_i8_stride(v.dim) : 0);
     size_t o_rpi = carve(npair * 8), o_rpn = carve(npair * 4), o_rps = carve(npair * 4), o_rpo = carve(npair * 8);
     size_t o_rc = carve(nnode * 4), o_rpf = carve(nnode * 4), o_rio = carve(nnode * 4);
     size_t o_rbs = carve(rg ? 2 * ((nnode + kPairScanChunk - 1) / kPairScanChunk + 1) * 4 : 0);
@@ -958,6 +999,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     // small per-query scans (few candidates): smaller blocks, more of them per CU, so that the
     // latency-bound prologue/selection phases of one query overlap the streaming of others
     // (two-word codes are built for 8 waves per SIMD: whole-CU occupancy with 512-thread blocks)
+    pl.leaf_grouped = v.code_kind == CUDDLE_CODE_BINARY && leaf_grouped_wanted(ix, std::min(nq, kMaxChunk), pl.lstride);
     pl.scan_threads = (pl.cstride <= 16384 && v.words != 2) ? 256 : kScanThreads;
     if (v.code_kind == CUDDLE_CODE_RABITQ) pl.scan_threads = 1024; // two blocks of 16 waves per CU: the LDS holds no more blocks, the registers this many waves
     if (const char *e = getenv("CUDDLE_SCAN_THREADS")) {  // tuning aid; the kernels are bounded at 512 threads
@@ -1400,10 +1442,25 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
     // (nq <= kMaxChunk = 4096)
     mark(ix, s, CUDDLE_STAGE_SCAN_PREP);
     const uint32_t tstride = pl.lstride + 4;
+    const bool by_leaf = pl.leaf_grouped && v.code_kind == CUDDLE_CODE_BINARY;
     hipLaunchKernelGGL(cand_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, pl.leaves, pl.lstride, pl.lcount, nq,
-                       pl.cand_count);
+                       pl.cand_count, by_leaf ? pl.rq_cnt : (uint32_t *)nullptr, v.n_nodes + 1);
     hipLaunchKernelGGL(scan_tables_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, pl.leaves, pl.lstride, pl.lcount,
-                       pl.cand_count, nq, pl.leaf_tables, tstride);
+                       pl.cand_count, nq, pl.leaf_tables, tstride, by_leaf ? pl.rq_cnt : (uint32_t *)nullptr,
+                       reinterpret_cast<uint2 *>(pl.rq_pinfo), pl.rq_pnode, pl.rq_pslot);
+    if (by_leaf) { // the pairs in leaf order, cut into work items of at most 64 queries
+        const uint32_t n = v.n_nodes, nb = (n + kPairScanChunk - 1) / kPairScanChunk;
+        const bool self_carry = nb <= 16;
+        if (!self_carry) {
+            hipLaunchKernelGGL(pair_block_sums_kernel, dim3(nb), dim3(256), 0, s, pl.rq_cnt, n, pl.rq_bsum, nb);
+            hipLaunchKernelGGL(pair_block_scan_kernel, dim3(1), dim3(1024), 0, s, pl.rq_bsum, nb, n, pl.rq_poff, pl.rq_ioff);
+        }
+        hipLaunchKernelGGL(pair_scan_kernel, dim3(nb), dim3(256), 0, s, pl.rq_cnt, n, self_carry ? nullptr : pl.rq_bsum, nb, pl.rq_poff,
+                           pl.rq_ioff, reinterpret_cast<uint4 *>(pl.rq_items), (const uint2 *)nullptr);
+        hipLaunchKernelGGL(leaf_pair_fill_kernel, dim3((pl.lstride + 255) / 256, nq), dim3(256), 0, s,
+                           reinterpret_cast<const uint2 *>(pl.rq_pinfo), pl.rq_pnode, pl.rq_pslot, pl.lcount, pl.lstride, nq, pl.rq_poff,
+                           reinterpret_cast<uint2 *>(pl.rq_psorted));
+    }
     mark(ix, s, CUDDLE_STAGE_SCAN);
     if (v.code_kind == CUDDLE_CODE_RABITQ) {
         static const bool rabitq_exact_all = getenv("CUDDLE_RABITQ_EXACT_ALL") != nullptr; // A/B aid: no bounds, every estimate exact
@@ -1450,9 +1507,20 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
         HIP_TRY(hipGetLastError());
         return CUDDLE_OK;
     }
+    if (by_leaf) {
+        const uint32_t total = nq * pl.lstride, max_items = total / kGroupPairs + std::min(v.n_nodes, total) + 1;
+        if (v.dim < 255)
+            hipLaunchKernelGGL(leaf_kernel8_for(v.words), dim3(max_items), dim3(128), 0, s, v, pl.rq_ioff + v.n_nodes,
+                               reinterpret_cast<const uint4 *>(pl.rq_items), reinterpret_cast<const uint2 *>(pl.rq_psorted), pl.qcodes,
+                               reinterpret_cast<uint8_t *>(pl.gdist), pl.cstride);
+        else
+            hipLaunchKernelGGL(leaf_kernel16_for(v.words), dim3(max_items), dim3(128), 0, s, v, pl.rq_ioff + v.n_nodes,
+                               reinterpret_cast<const uint4 *>(pl.rq_items), reinterpret_cast<const uint2 *>(pl.rq_psorted), pl.qcodes,
+                               reinterpret_cast<uint16_t *>(pl.gdist), pl.cstride);
+    }
     hipLaunchKernelGGL(scan_kernel_for(v.dim, v.words), dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, pl.qcodes,
                        pl.leaf_tables, tstride, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, (void *)pl.gdist, pl.cstride,
-                       pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, ghist);
+                       pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, ghist, by_leaf ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
 }
@@ -1920,7 +1988,7 @@ extern "C" cuddle_status cuddle_scan_read_ceiling(cuddle_index *idx, const float
     auto scan_once = [&](uint32_t b) {
         hipLaunchKernelGGL(scan_kernel_for(v.dim, v.words), dim3(n_queries), dim3(pl.scan_threads), pl.scan_lds, s, v, codes_of(b),
                            tables_of(b), tstride, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, (void *)pl.gdist, pl.cstride,
-                           pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, (uint32_t *)nullptr);
+                           pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, (uint32_t *)nullptr, 0u);
     };
     auto body = [&]() -> cuddle_status {
         for (uint32_t b = 0; b < n_batches; ++b) read_once(b); // one untimed round

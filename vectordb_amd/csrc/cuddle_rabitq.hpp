@@ -344,11 +344,6 @@ __device__ __forceinline__ float rabitq_bounds_from_sum(int S, float delta, floa
     return est + E + round_out;
 }
 
-// popcount(x) + acc in one instruction (the compiler otherwise splits it into a count and a three-way add).
-__device__ __forceinline__ void popc_acc(uint32_t &acc, uint32_t x) {
-    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x));
-}
-
 // Upper bound est~ + E (returned) and lower bound est~ - E (lb) of the estimate of vector i of a leaf (codes
 // word-major [w][n]); see the section comment. Both are rounded outwards. `codes`, `n` and `row` (the query's row
 // of rabitq_query_planes_kernel) are the same for every lane of the wave: the code words are loaded from a scalar
