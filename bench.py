@@ -567,6 +567,12 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
     rabitq = cfg["code_kind"] == "rabitq"
     code_bytes = (4 * ((cfg["dim"] + 31) // 32) + 8) if rabitq else 8 * ((cfg["dim"] + 63) // 64)
     scan_kernel = "scan_select_rabitq_kernel" if rabitq else "scan_select_hamming_kernel"
+    # binary codes of 512 bits and more, batches that reach a leaf several times over: the scan goes leaf by leaf
+    # (leaf_hamming_kernel reads a leaf's codes once per 64 queries, scan_select_hamming_kernel selects from the
+    # distances it hands over); the scan stage is then those two launches
+    scan_mode = dev_index.scan_mode(nq, probes) if not rabitq else "per_query"
+    if scan_mode == "leaf_by_leaf":
+        scan_kernel = "leaf_hamming_kernel + scan_select_hamming_kernel"
     scan_bytes = stats["vectors_scanned"] * code_bytes           # algorithmic bytes of one launch (this rank, last step)
     rerank_bytes = stats["vectors_reranked"] * 4 * cfg["dim"]
     n_timed = max(stage["searches"], 1)
@@ -576,11 +582,12 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
     pmc_path = os.path.join(ROOT, "profiles", f"pmc_hbm_traffic_{name}.json")
     if world == 1 and os.path.exists(pmc_path):  # measured separately under rocprofv3 --pmc (it cannot run inside this process)
         pmc = json.load(open(pmc_path))
-        traffic = pmc["kernels"].get(scan_kernel, {}).get("traffic_bytes_per_launch")
+        parts = [pmc["kernels"].get(kn.strip(), {}).get("traffic_bytes_per_launch") for kn in scan_kernel.split("+")]
+        traffic = sum(parts) if all(p is not None for p in parts) else None
         traffic_src = os.path.relpath(pmc_path, ROOT)
     code_array = dev_index_codes_bytes = (n_total // world) * code_bytes
     fits_l3 = code_array <= (256 << 20)
-    roofline = dict(bound="hbm", kernel=scan_kernel, achieved=achieved, peak=HBM_PEAK_GBPS,
+    roofline = dict(bound="hbm", kernel=scan_kernel, scan_mode=scan_mode, achieved=achieved, peak=HBM_PEAK_GBPS,
                     unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=traffic, traffic_source=traffic_src,
                     traffic_kind="L2-miss (fabric) bytes per launch from TCC FETCH_SIZE + WRITE_SIZE; FETCH_SIZE also counts "
                                  "requests served by the 256 MiB Infinity Cache, so this is HBM traffic only for arrays "
@@ -589,11 +596,18 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
                     stage_ms_per_step={n: stage[n] / n_timed for n in _ffi.STAGE_NAMES},
                     rerank_GBps=(rerank_bytes / (stage["rerank"] / n_timed * 1e-3) / 1e9) if stage["rerank"] > 0 else 0.0,
                     code_array_bytes=code_array, code_array_fits_infinity_cache=fits_l3,
-                    note=("the whole code array fits the 256 MiB Infinity Cache: achieved is on-die cache bandwidth as much as "
+                    note=("leaf by leaf: achieved counts the reference's bytes (every query reads the codes of its own candidates, "
+                          "hierarchical.rs:591-641) over the time of the two launches that replace those reads - a leaf's codes are "
+                          "fetched once per 64 queries that reach it, so the figure may pass what memory could deliver per query "
+                          "(frac > 1) and `traffic` is far below the algorithmic bytes; what limits the launches is integer issue "
+                          "(one xor and one counting add per 32 code bits and pair) and, for the selection, LDS; "
+                          if scan_mode == "leaf_by_leaf" else "") +
+                         ("the whole code array fits the 256 MiB Infinity Cache: achieved is on-die cache bandwidth as much as "
                           "HBM bandwidth (see roofline_hbm_resident for the same kernel on a code array that does not fit); "
                           if fits_l3 else "the code array is larger than the 256 MiB Infinity Cache: the scan streams from HBM; ") +
-                         f"achieved = algorithmic code bytes / mean duration of the scan kernel alone (HIP events around that launch, on every {STAGE_SAMPLE}th search of the timed loop; "
-                         f"the candidate-count / block-order kernel before it is stage scan_prep); the timed loop rotates {N_BATCHES} query batches")
+                         f"achieved = algorithmic code bytes / mean duration of the scan launch(es) alone (HIP events around them, on every {STAGE_SAMPLE}th search of the timed loop, "
+                         f"which runs its stages on one stream; the candidate-count / block-order / pair-order kernels before them are stage scan_prep); "
+                         f"the timed loop rotates {N_BATCHES} query batches")
     del dev_index_codes_bytes
     # what the scan's reads alone cost: a kernel that issues exactly the scan's loads (same leaves, same pieces, as many
     # in flight) and nothing else, timed back to back with the scan kernel on the first batch
@@ -606,7 +620,7 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
             roofline.update(ceiling_GBps=code_bytes / (read_ms * 1e-3) / 1e9, ceiling_launch_ms=read_ms,
                             scan_launch_ms_same_run=scan_ms_same, frac_of_ceiling=read_ms / scan_ms_same,
                             ceiling_queries_per_launch=nqc,
-                            ceiling_note="ceiling = the scan's own reads with no arithmetic, histogram or selection behind them "
+                            ceiling_note="ceiling = the per-query scan's own reads with no arithmetic, histogram or selection behind them "
                                          "(scan_read_ceiling_kernel: same grid, block, LDS size, tables and loads); both kernels "
                                          f"timed with HIP events over 5 rounds of the same {N_BATCHES} rotating batches")
         except _ffi.CuddleError as e:
@@ -708,7 +722,7 @@ def compact_config(big, wall_s):
             "roofline": {key: r[key] for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
                                                  "algorithmic_bytes_per_launch", "avg_launch_ms", "rerank_GBps",
                                                  "code_array_bytes", "code_array_fits_infinity_cache", "ceiling_GBps",
-                                                 "frac_of_ceiling") if key in r},
+                                                 "frac_of_ceiling", "scan_mode") if key in r},
             "cpu_baseline": cpu, "wall_s": wall_s}
 
 

@@ -334,6 +334,12 @@ cuddle_status cuddle_route_filter_error(cuddle_index *idx, const float *queries,
                                         uint32_t n_queries, uint32_t dim,
                                         uint32_t probes_per_level, uint32_t level,
                                         float *out_max_ratio, float *out_max_abs);
+/* How a batch of n_queries would scan its leaves (no counterpart in the reference, whose scan is per query,
+ * hierarchical.rs:591-641): *out_mode = 0 per query (one block streams the codes of a query's leaves), 1 leaf by leaf
+ * (binary codes of 512 bits and more, when the batch reaches a leaf several times over: a leaf's codes are read once
+ * per 64 queries and the distances handed to the per-query selection). The results are the same either way. */
+cuddle_status cuddle_scan_mode(cuddle_index *idx, uint32_t n_queries, uint32_t probes_per_level,
+                               uint32_t *out_mode);
 /* Measuring aid, no counterpart in the reference: what the leaf scan's memory accesses cost by themselves.
  * d_queries: [n_batches][n_queries][dim] on the device (1..64 batches of one chunk each). Every batch is routed
  * once; then `reps` rounds over the batches are timed (HIP events, null stream), first with a kernel that issues

@@ -117,6 +117,7 @@ SIGNATURES = {
     "cuddle_binary_threshold": (C.c_float, [_vp, _u64, _u32]),
     "cuddle_route_batch": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _u32, _vp]),
     "cuddle_route_filter_error": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "cuddle_scan_mode": (_int, [_vp, _u32, _u32, _vp]),
     "cuddle_scan_read_ceiling": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "cuddle_index_leaf_stride": (_int, [_vp, _u32, _vp]),
     "cuddle_route_batch_device": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _u32, _vp, _vp]),

@@ -1935,6 +1935,18 @@ extern "C" float cuddle_binary_threshold(const float *vectors, uint64_t n, uint3
     return total / (float)count;
 }
 
+extern "C" cuddle_status cuddle_scan_mode(cuddle_index *idx, uint32_t n_queries, uint32_t probes_per_level, uint32_t *out_mode) {
+    if (!idx || !out_mode) return fail(CUDDLE_ERR_BAD_ARG, "null argument");
+    if (probes_per_level == 0) return fail(CUDDLE_ERR_BAD_ARG, "probes_per_level must be >= 1");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    const uint32_t lstride = plan_leaf_stride(idx, probes_per_level);
+    const uint32_t piece = n_queries > kMaxChunk ? (n_queries + 2 * ((n_queries + 2 * kMaxChunk - 1) / (2 * kMaxChunk)) - 1) /
+                                                       (2 * ((n_queries + 2 * kMaxChunk - 1) / (2 * kMaxChunk)))
+                                                 : n_queries;
+    *out_mode = idx->dev.code_kind == CUDDLE_CODE_BINARY && leaf_grouped_wanted(idx, std::max(piece, 1u), lstride) ? 1u : 0u;
+    return CUDDLE_OK;
+}
+
 extern "C" cuddle_status cuddle_scan_read_ceiling(cuddle_index *idx, const float *d_queries, uint32_t n_batches,
                                                   uint32_t n_queries, uint32_t dim, uint32_t k, uint32_t probes_per_level,
                                                   uint32_t rerank_factor, uint32_t reps, float *out_read_ms, float *out_scan_ms,

@@ -346,6 +346,12 @@ class DeviceIndex:
                                                        _ffi.ptr(ratio), _ffi.ptr(err)))
         return float(ratio[0]), float(err[0])
 
+    def scan_mode(self, n_queries: int, probes_per_level: int) -> str:
+        """How a batch of this size scans its leaves: "per_query" or "leaf_by_leaf" (cuddle_scan_mode)."""
+        out = C.c_uint32(0)
+        _ffi.check(self._lib.cuddle_scan_mode(self._handle, n_queries, probes_per_level, C.byref(out)))
+        return "leaf_by_leaf" if out.value else "per_query"
+
     def scan_read_ceiling(self, d_batches, k: int, probes_per_level: int, rerank_factor: int, reps: int = 5):
         """d_batches: float32 CUDA tensor [n_batches, nq, dim]. (read_ms, scan_ms, code_bytes): mean launch time of the
         kernel that only issues the Hamming scan's reads, of the scan kernel itself (both going round the batches
