@@ -170,3 +170,46 @@ def test_failed_half_proofs_on_per_query_frontiers_take_the_exact_path(gpu):
     assert first["route_fallbacks"] >= 8, first
     assert late["route_fallbacks"] * 4 <= first["route_fallbacks"], (first, late)
     assert np.array_equal(ids, ids_x) and np.array_equal(dist.view(np.uint32), dist_x.view(np.uint32)) and np.array_equal(cnt, cnt_x)
+
+
+def test_a_level_table_beyond_the_infinity_cache_takes_half_operands_by_itself(gpu):
+    """No size override: a last level of 81^3 = 531 441 nodes of 128-d rows has a 272 MB split table, more than
+    the 256 MiB Infinity Cache, so its per-query frontiers are contracted from half-precision operands by the
+    library's own rule. The results must be the all-exact path's on every query and the CPU oracle's on a sample
+    (the oracle searches a host copy that holds the whole tree and the leaves these queries reach); that the rule
+    fired is shown on a second handle with one spare candidate, where half-precision proofs fail in numbers (the
+    split filter does not read that setting)."""
+    import torch
+
+    import bench
+    from vectordb_amd.synthetic import build_tree_index_on_device
+
+    assert "CUDDLE_GROUPED_HALF_MIN_BYTES" not in os.environ
+    device = torch.device("cuda", gpu)
+    dti, queries = build_tree_index_on_device(128, 81, 3, 4, device, seed=0xBEEF, n_queries=256, metric=_ffi.METRIC_L2,
+                                              style="sift")
+    n_last = 81 ** 3
+    assert n_last * 128 * 4 > 256 << 20
+    k, probes, rf = 10, 100, 10
+    dev = dti.create(gpu)
+    nq = queries.shape[0]
+    out = (torch.empty((nq, k), dtype=torch.int64, device=device), torch.empty((nq, k), dtype=torch.float32, device=device),
+           torch.empty((nq,), dtype=torch.int32, device=device))
+    exact = tuple(torch.empty_like(t) for t in out)
+    for _ in range(3):  # (the first calls are the ones the failure feedback has not judged yet: every one must be exact)
+        dev.search_batch_device(queries, k, probes, rf, 0, *out)
+        torch.cuda.synchronize()
+        dev.search_batch_device(queries, k, probes, rf, _ffi.SEARCH_ROUTE_EXACT_ONLY, *exact)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], exact[0]) and torch.equal(out[1].view(torch.int32), exact[1].view(torch.int32))
+        assert torch.equal(out[2], exact[2])
+    chk = bench.oracle_spot_check(dti, dev, queries, k, probes, rf, *out, n_sample=32)
+    assert chk["oracle_rc"] == 0 and chk["gpu_ids_identical_on_sample"] and chk["gpu_dist_bits_identical_on_sample"], chk
+    os.environ["CUDDLE_ROUTE_MARGIN_HALF"] = "1"
+    try:
+        other = dti.create(gpu)
+        q = queries.cpu().numpy()
+        _, _, _, first = other.search_batch(q, k, probes, rf, want_stats=True)
+    finally:
+        del os.environ["CUDDLE_ROUTE_MARGIN_HALF"]
+    assert first["route_fallbacks"] >= 8, first
