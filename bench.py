@@ -16,12 +16,18 @@ and the rerank sweep {5,10,25,50,100} are the reference's GIST settings
 (/root/reference/benches/gist_benchmark.rs:177-183); the timed operating point is the cheapest
 sweep point whose recall@10 against brute-force ground truth is >= 0.95.
 
-Rank 0 prints ONE JSON line: metric/value/unit (whole-job queries per second), the timing
-contract fields, recall, batch-latency percentiles, `roofline` (dominant kernel = the code scan:
-algorithmic code bytes per launch / mean launch time from HIP events on the launch stream, against
-the 8 TB/s HBM peak), `roofline_hbm_resident` (the same kernel on a 10M x 960-d index whose 1.2 GB
-of codes cannot sit in the 256 MiB Infinity Cache; default workload at N = 1 only) and
-`cpu_baseline` (the CPU oracle timed on this host).
+Rank 0 prints ONE JSON line: metric/value/unit (whole-job queries per second on the default
+workload), the timing contract fields, recall, batch-latency percentiles, `roofline` (dominant
+kernel = the code scan: algorithmic code bytes per launch / mean launch time from HIP events on the
+launch stream, against the 8 TB/s HBM peak; which scan ran - per query or leaf by leaf - is
+`scan_mode`, and `ceiling_GBps` is the rate of the per-query scan's own loads with nothing behind
+them, timed in the same run), `cpu_baseline` (the CPU oracle timed on this host, and whether the GPU's
+ids and distance bits equal its results) and, at N = 1 on the default workload, `configs`: the same
+measurement for every other configuration of BASELINE.json (gist10m = the default's shape on a code
+array that cannot sit in the 256 MiB Infinity Cache, also reported as `roofline_hbm_resident`;
+sift1m; rabitq10m; shard12m; shard125m), each with its own recall sweep, stage times, roofline block
+and full-size oracle check, within CUDDLE_BENCH_BUDGET_S seconds (default 400; what does not fit is
+named in `configs_skipped`). N > 1 adds `comm_ms`: every collective of the sharded protocol by name.
 """
 from __future__ import annotations
 
