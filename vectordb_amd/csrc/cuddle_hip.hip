@@ -1465,6 +1465,9 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
     if (v.code_kind == CUDDLE_CODE_RABITQ) {
         static const bool rabitq_exact_all = getenv("CUDDLE_RABITQ_EXACT_ALL") != nullptr; // A/B aid: no bounds, every estimate exact
         const float *rq = reinterpret_cast<const float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
+        // bound tiles cut every 64 scan positions across leaf ends (lanes address the code array by 32-bit word offsets)
+        static const bool pack_env = !(getenv("CUDDLE_RQ_PACK") && atoi(getenv("CUDDLE_RQ_PACK")) == 0); // A/B aid
+        const bool pack_ok = pack_env && v.n_vectors * (uint64_t)v.words32 < (1ull << 32);
         uint32_t pre_bounds = 0;
         if (pl.rq_grouped && !rabitq_exact_all) {
             // the (query, leaf) pairs of the leaf lists in leaf order, cut into work items; then the bounds of every
@@ -1495,7 +1498,7 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
         hipLaunchKernelGGL(scan_select_rabitq_kernel, dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, rq, qn, pl.leaf_tables,
                            tstride, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, reinterpret_cast<float *>(pl.gdist),
                            pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, rabitq_exact_all ? 1u : 0u,
-                           &ix->d_stats->rq_exact, pl.rq_rows, pre_bounds);
+                           &ix->d_stats->rq_exact, pl.rq_rows, pre_bounds, pack_ok ? 1u : 0u);
         if (pre_bounds == 2) { // checking mode: any bound that differs from the per-query kernel's fails the search
             DevStats h;
             HIP_TRY(hipStreamSynchronize(s));

@@ -344,11 +344,14 @@ __device__ __forceinline__ float rabitq_bounds_from_sum(int S, float delta, floa
     return est + E + round_out;
 }
 
-// Upper bound est~ + E (returned) and lower bound est~ - E (lb) of the estimate of vector i of a leaf (codes
-// word-major [w][n]); see the section comment. Both are rounded outwards. `codes`, `n` and `row` (the query's row
-// of rabitq_query_planes_kernel) are the same for every lane of the wave: the code words are loaded from a scalar
-// row base + the lane's own 4 i bytes, and the planes come through scalar loads.
-__device__ __forceinline__ float rabitq_bounds(const uint32_t *__restrict__ codes, uint32_t n, uint32_t i, uint32_t words32,
+// Upper bound est~ + E (returned) and lower bound est~ - E (lb) of the estimate of one vector; see the section
+// comment. Both are rounded outwards. Code word w of the vector is codes[off + w * n] (leaf blocks are word-major
+// [w][n]). `row` (the query's row of rabitq_query_planes_kernel) is the same for every lane of the wave: the planes
+// come through scalar loads. UNIFORM: `codes` and `n` are wave-uniform too (the wave's lanes are consecutive vectors
+// of one leaf, off = the lane's place in it), so the word's address is a scalar row base plus the lane's own bytes;
+// otherwise every lane brings its own leaf (off = where the vector's word 0 lies in the whole code array).
+template <bool UNIFORM>
+__device__ __forceinline__ float rabitq_bounds(const uint32_t *__restrict__ codes, uint32_t n, uint32_t off, uint32_t words32,
                                                const uint32_t *__restrict__ row, float qnorm, float norm, float ipoo, float &lb) {
     if (norm < 1e-10f) { // exact (rabitq.rs:342-349)
         lb = qnorm * qnorm;
@@ -363,7 +366,14 @@ __device__ __forceinline__ float rabitq_bounds(const uint32_t *__restrict__ code
         constexpr uint32_t CH = decltype(ch)::value;
         uint32_t cw[CH];
 #pragma unroll
-        for (uint32_t u = 0; u < CH; ++u) cw[u] = (codes + (uint64_t)(w + u) * n)[i];
+        for (uint32_t u = 0; u < CH; ++u) {
+            if (UNIFORM) {
+                cw[u] = (codes + (uint64_t)(w + u) * n)[off];
+            } else {
+                cw[u] = codes[off];
+                off += n;
+            }
+        }
 #pragma unroll
         for (uint32_t u = 0; u < CH; ++u) {
             const uint32_t *pw = row + 8 + kRqWordStride * (w + u);
@@ -435,7 +445,7 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
                           uint32_t tstride, uint32_t lcap, uint32_t tcap, uint32_t rerank_k,
                           uint32_t dist_cap, float *gest, uint32_t gest_stride, uint32_t *sel_pos, uint32_t *sel_key,
                           uint32_t sel_stride, uint32_t *sel_count, uint32_t *cand_count, uint32_t exact_all,
-                          unsigned long long *stats, const uint32_t *__restrict__ qrows, uint32_t pre_bounds) {
+                          unsigned long long *stats, const uint32_t *__restrict__ qrows, uint32_t pre_bounds, uint32_t pack_ok) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const uint32_t D = ix.dim, W32 = ix.words32;
@@ -472,21 +482,49 @@ scan_select_rabitq_kernel(IndexDev ix, const float *rq_all, const float *qnorm_a
         }
         // this query's row of quantised magnitudes: a wave-uniform address, so its words are read into scalar registers
         const uint32_t *row = qrows + (uint64_t)__builtin_amdgcn_readfirstlane(q) * rq_plane_stride(W32);
-        for (uint32_t t = w; t < ntiles && pre_bounds != 1; t += nw) {
-            // one tile = 64 consecutive vectors of one leaf: everything but the lane's own vector is the same for the wave
-            const uint32_t tile = __builtin_amdgcn_readfirstlane(s.tiles[t]), sl = tile >> 12, i = ((tile & 4095u) << 6) + lane;
-            const uint32_t base = __builtin_amdgcn_readfirstlane(s.lscan[sl]);
-            const uint32_t n = __builtin_amdgcn_readfirstlane(s.lscan[sl + 1]) - base;
-            const uint32_t beg = __builtin_amdgcn_readfirstlane(s.lbeg[sl]);
-            if (i < n) {
-                const uint32_t pos = beg + i;
-                float lb;
-                const float ub = rabitq_bounds(ix.rq_codes + (uint64_t)beg * W32, n, i, W32, row, qnorm, ix.rq_norm[pos], ix.rq_ipoo[pos], lb);
+        // Tiles of 64 consecutive scan positions, whatever leaves they fall into (a leaf of 103 vectors cut by itself
+        // would fill its second wave to 39 lanes of 64, and this loop is bound by the vector unit's issue rate). The
+        // leaf slot of every tile's first position goes through the member list's storage, unused until tau is known.
+        // (pack_ok == 0, a code array of 2^32 words or more: the tiles cut at leaf ends by scan_build_tiles instead.)
+        const uint32_t nt = pack_ok ? (C + 63) >> 6 : ntiles;
+        const bool slot_tab = pack_ok && nt <= kRqListCap;
+        if (slot_tab && pre_bounds != 1) {
+            for (uint32_t t = tid; t < nt; t += blockDim.x) r.list[t] = scan_slot_of(s.lscan, nl, 64 * t);
+            __syncthreads();
+        }
+        for (uint32_t t = w; t < nt && pre_bounds != 1; t += nw) {
+            uint32_t sl0, first;
+            if (pack_ok) {
+                first = 64 * t;
+                sl0 = __builtin_amdgcn_readfirstlane(slot_tab ? r.list[t] : scan_slot_of(s.lscan, nl, first));
+            } else {
+                const uint32_t tile = __builtin_amdgcn_readfirstlane(s.tiles[t]);
+                sl0 = tile >> 12;
+                first = __builtin_amdgcn_readfirstlane(s.lscan[sl0]) + ((tile & 4095u) << 6);
+            }
+            const uint32_t end0 = __builtin_amdgcn_readfirstlane(s.lscan[sl0 + 1]);
+            const uint32_t lim = min(pack_ok ? C : end0, first + 64); // the tile: scan positions [first, lim)
+            const uint32_t i = first + lane, ic = min(i, lim - 1);
+            float ub, lb;
+            if (lim <= end0) {
+                // the whole tile lies in one leaf: everything but the lane's own vector is the same for the wave
+                const uint32_t base = __builtin_amdgcn_readfirstlane(s.lscan[sl0]), n = end0 - base;
+                const uint32_t beg = __builtin_amdgcn_readfirstlane(s.lbeg[sl0]);
+                const uint32_t k = ic - base, pos = beg + k;
+                ub = rabitq_bounds<true>(ix.rq_codes + (uint64_t)beg * W32, n, k, W32, row, qnorm, ix.rq_norm[pos], ix.rq_ipoo[pos], lb);
+            } else {
+                uint32_t sl = sl0;
+                while (ic >= s.lscan[sl + 1]) ++sl; // (skips empty leaves as well)
+                const uint32_t base = s.lscan[sl], n = s.lscan[sl + 1] - base, beg = s.lbeg[sl];
+                const uint32_t k = ic - base, pos = beg + k;
+                ub = rabitq_bounds<false>(ix.rq_codes, n, beg * W32 + k, W32, row, qnorm, ix.rq_norm[pos], ix.rq_ipoo[pos], lb);
+            }
+            if (i < lim) {
                 if (pre_bounds == 2 && stats &&
-                    (__float_as_uint(ub) != __float_as_uint(ge[base + i]) || __float_as_uint(lb) != __float_as_uint(glb[base + i])))
+                    (__float_as_uint(ub) != __float_as_uint(ge[i]) || __float_as_uint(lb) != __float_as_uint(glb[i])))
                     atomicAdd(&stats[2], 1ull);
-                est_put(base + i, ub);
-                glb[base + i] = lb;
+                est_put(i, ub);
+                glb[i] = lb;
             }
         }
         __syncthreads();
