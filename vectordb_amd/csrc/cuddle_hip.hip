@@ -1466,7 +1466,8 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
         static const bool rabitq_exact_all = getenv("CUDDLE_RABITQ_EXACT_ALL") != nullptr; // A/B aid: no bounds, every estimate exact
         const float *rq = reinterpret_cast<const float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
         // bound tiles cut every 64 scan positions across leaf ends (lanes address the code array by 32-bit word offsets)
-        static const bool pack_env = !(getenv("CUDDLE_RQ_PACK") && atoi(getenv("CUDDLE_RQ_PACK")) == 0); // A/B aid
+        const char *pe = getenv("CUDDLE_RQ_PACK"); // A/B and test aid, read at every call: 0 = tiles cut at leaf ends
+        const bool pack_env = !(pe && atoi(pe) == 0);
         const bool pack_ok = pack_env && v.n_vectors * (uint64_t)v.words32 < (1ull << 32);
         uint32_t pre_bounds = 0;
         if (pl.rq_grouped && !rabitq_exact_all) {

@@ -1671,6 +1671,7 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
     __shared__ uint32_t misc[4];
     __shared__ uint32_t wred[2 * (THREADS / 64)];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    CUDDLE_STAMP(8, 6);
     if (skip && skip[q]) return;
     if (ncount) { // per-query frontier: its own width, and no more candidates than it has nodes
         n = min(n, ncount[q]);
