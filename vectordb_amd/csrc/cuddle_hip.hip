@@ -222,7 +222,7 @@ struct Plan {
     // of the leaf lists in leaf order, the work items cut from them
     int8_t *rq_i8 = nullptr;
     uint32_t *rq_pinfo = nullptr, *rq_pnode = nullptr, *rq_pslot = nullptr, *rq_psorted = nullptr;
-    uint32_t *rq_cnt = nullptr, *rq_poff = nullptr, *rq_ioff = nullptr, *rq_bsum = nullptr, *rq_items = nullptr;
+    uint32_t *rq_cnt = nullptr, *rq_poff = nullptr, *rq_ioff = nullptr, *rq_bsum = nullptr, *rq_items = nullptr, *rq_order = nullptr;
     bool rq_grouped = false;
     bool leaf_grouped = false; // binary codes: the Hamming scan leaf by leaf (leaf_hamming_kernel), same pair arrays
     uint32_t *level_fc = nullptr; // [n_levels + 1][qc] frontier size of every query at every level (stats variant)
@@ -364,7 +364,7 @@ static GroupedKernel grouped_kernel_for(uint32_t dim, uint32_t metric) {
 #define CUDDLE_SCAN_U2 8 // tiles a wave keeps in flight when a code is one 16-byte slot (dim <= 128)
 #endif
 using ScanKernel = void (*)(IndexDev, const uint64_t *, const uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
-                            void *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t);
+                            void *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *);
 
 // The Hamming scan instantiation for a code of `words` u64 (distances in u8 when dim < 255).
 static ScanKernel scan_kernel_for(uint32_t dim, uint32_t words) {
@@ -751,6 +751,8 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     (void)hipFuncSetAttribute((const void *)selection_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_kernel_for(v.dim, v.words), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_all_hamming_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)select_rows_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)select_rows_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<256, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -835,8 +837,8 @@ static bool rq_grouped_wanted(uint32_t nq, uint32_t dim, uint32_t lstride) {
     return false;
 }
 
-using LeafKernel8 = void (*)(IndexDev, const uint32_t *, const uint4 *, const uint2 *, const uint64_t *, uint8_t *, uint32_t);
-using LeafKernel16 = void (*)(IndexDev, const uint32_t *, const uint4 *, const uint2 *, const uint64_t *, uint16_t *, uint32_t);
+using LeafKernel8 = void (*)(IndexDev, const uint32_t *, const uint4 *, const uint32_t *, const uint2 *, const uint64_t *, uint8_t *, uint32_t);
+using LeafKernel16 = void (*)(IndexDev, const uint32_t *, const uint4 *, const uint32_t *, const uint2 *, const uint64_t *, uint16_t *, uint32_t);
 // The leaf-by-leaf Hamming kernel for a code of `words` u64 (one instantiation per width scan_kernel_for() knows); null otherwise.
 static LeafKernel8 leaf_kernel8_for(uint32_t words) {
     switch (words) {
@@ -908,9 +910,10 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     const size_t npair = rg ? qc * pl.lstride : 0, nnode = rg ? (size_t)v.n_nodes + 1 : 0;
     size_t o_ri8 = carve(rq && pl.rq_grouped ? qc * (size_t)rq_i8_stride(v.dim) : 0);
     size_t o_rpi = carve(npair * 8), o_rpn = carve(npair * 4), o_rps = carve(npair * 4), o_rpo = carve(npair * 8);
-    size_t o_rc = carve(nnode * 4), o_rpf = carve(nnode * 4), o_rio = carve(nnode * 4);
+    size_t o_rc = carve((nnode + (rg ? 2 * kWorkBins : 0)) * 4), o_rpf = carve(nnode * 4), o_rio = carve(nnode * 4); // (+ the items' work classes)
     size_t o_rbs = carve(rg ? 2 * ((nnode + kPairScanChunk - 1) / kPairScanChunk + 1) * 4 : 0);
     size_t o_rit = carve(rg ? (npair / kGroupPairs + nnode + 1) * 16 : 0);
+    size_t o_rod = carve(pl.leaf_grouped ? (npair / kGroupPairs + nnode + 1) * 4 : 0);
     if (!b) return off;
     pl.qcodes = (uint64_t *)(b + o_qcodes);
     pl.frontier[0] = (uint32_t *)(b + o_f0); pl.frontier[1] = (uint32_t *)(b + o_f1);
@@ -940,6 +943,7 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     pl.rq_psorted = (uint32_t *)(b + o_rpo);
     pl.rq_cnt = (uint32_t *)(b + o_rc); pl.rq_poff = (uint32_t *)(b + o_rpf); pl.rq_ioff = (uint32_t *)(b + o_rio);
     pl.rq_bsum = (uint32_t *)(b + o_rbs); pl.rq_items = (uint32_t *)(b + o_rit);
+    pl.rq_order = (uint32_t *)(b + o_rod);
     return off;
 }
 
@@ -1443,8 +1447,12 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
     mark(ix, s, CUDDLE_STAGE_SCAN_PREP);
     const uint32_t tstride = pl.lstride + 4;
     const bool by_leaf = pl.leaf_grouped && v.code_kind == CUDDLE_CODE_BINARY;
+    // heaviest items first when leaves are reached often enough for items of very different sizes (where a leaf sees
+    // two or three queries the items are all small, and leaf order keeps neighbouring leaves' codes together in time)
+    const bool order_items = by_leaf && (uint64_t)nq * pl.lstride >= 8ull * std::max<uint32_t>(ix->n_leaves, 1);
+    uint32_t *work_bins = pl.rq_cnt + v.n_nodes + 1;
     hipLaunchKernelGGL(cand_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, pl.leaves, pl.lstride, pl.lcount, nq,
-                       pl.cand_count, by_leaf ? pl.rq_cnt : (uint32_t *)nullptr, v.n_nodes + 1);
+                       pl.cand_count, by_leaf ? pl.rq_cnt : (uint32_t *)nullptr, v.n_nodes + 1 + 2 * kWorkBins);
     hipLaunchKernelGGL(scan_tables_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, pl.leaves, pl.lstride, pl.lcount,
                        pl.cand_count, nq, pl.leaf_tables, tstride, by_leaf ? pl.rq_cnt : (uint32_t *)nullptr,
                        reinterpret_cast<uint2 *>(pl.rq_pinfo), pl.rq_pnode, pl.rq_pslot);
@@ -1456,7 +1464,8 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
             hipLaunchKernelGGL(pair_block_scan_kernel, dim3(1), dim3(1024), 0, s, pl.rq_bsum, nb, n, pl.rq_poff, pl.rq_ioff);
         }
         hipLaunchKernelGGL(pair_scan_kernel, dim3(nb), dim3(256), 0, s, pl.rq_cnt, n, self_carry ? nullptr : pl.rq_bsum, nb, pl.rq_poff,
-                           pl.rq_ioff, reinterpret_cast<uint4 *>(pl.rq_items), (const uint2 *)nullptr);
+                           pl.rq_ioff, reinterpret_cast<uint4 *>(pl.rq_items), (const uint2 *)nullptr,
+                           order_items ? work_bins : (uint32_t *)nullptr, v.vec_off);
         hipLaunchKernelGGL(leaf_pair_fill_kernel, dim3((pl.lstride + 255) / 256, nq), dim3(256), 0, s,
                            reinterpret_cast<const uint2 *>(pl.rq_pinfo), pl.rq_pnode, pl.rq_pslot, pl.lcount, pl.lstride, nq, pl.rq_poff,
                            reinterpret_cast<uint2 *>(pl.rq_psorted));
@@ -1513,18 +1522,36 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
     }
     if (by_leaf) {
         const uint32_t total = nq * pl.lstride, max_items = total / kGroupPairs + std::min(v.n_nodes, total) + 1;
+        const bool order_items = (uint64_t)nq * pl.lstride >= 8ull * std::max<uint32_t>(ix->n_leaves, 1); // (as above)
+        const uint32_t *order = order_items ? pl.rq_order : nullptr;
+        if (order_items)
+            hipLaunchKernelGGL(item_scatter_kernel, dim3((max_items + 255) / 256), dim3(256), 0, s, v, pl.rq_ioff + v.n_nodes,
+                               reinterpret_cast<const uint4 *>(pl.rq_items), pl.rq_cnt + v.n_nodes + 1, pl.rq_order);
         if (v.dim < 255)
             hipLaunchKernelGGL(leaf_kernel8_for(v.words), dim3(max_items), dim3(128), 0, s, v, pl.rq_ioff + v.n_nodes,
-                               reinterpret_cast<const uint4 *>(pl.rq_items), reinterpret_cast<const uint2 *>(pl.rq_psorted), pl.qcodes,
-                               reinterpret_cast<uint8_t *>(pl.gdist), pl.cstride);
+                               reinterpret_cast<const uint4 *>(pl.rq_items), order, reinterpret_cast<const uint2 *>(pl.rq_psorted),
+                               pl.qcodes, reinterpret_cast<uint8_t *>(pl.gdist), pl.cstride);
         else
             hipLaunchKernelGGL(leaf_kernel16_for(v.words), dim3(max_items), dim3(128), 0, s, v, pl.rq_ioff + v.n_nodes,
-                               reinterpret_cast<const uint4 *>(pl.rq_items), reinterpret_cast<const uint2 *>(pl.rq_psorted), pl.qcodes,
-                               reinterpret_cast<uint16_t *>(pl.gdist), pl.cstride);
+                               reinterpret_cast<const uint4 *>(pl.rq_items), order, reinterpret_cast<const uint2 *>(pl.rq_psorted),
+                               pl.qcodes, reinterpret_cast<uint16_t *>(pl.gdist), pl.cstride);
     }
-    hipLaunchKernelGGL(scan_kernel_for(v.dim, v.words), dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, pl.qcodes,
-                       pl.leaf_tables, tstride, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, (void *)pl.gdist, pl.cstride,
-                       pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, ghist, by_leaf ? 1u : 0u);
+    if (by_leaf) {
+        // the distances are in the spill rows: histogram, threshold and selection from there, every query of the chunk resident
+        const size_t lds = select_rows_lds_bytes(v.dim, pl.lstride);
+        if (v.dim < 255)
+            hipLaunchKernelGGL(select_rows_kernel<uint8_t>, dim3(nq), dim3(512), lds, s, v, pl.leaf_tables, tstride, pl.lstride, pl.rerank_k,
+                               reinterpret_cast<const uint8_t *>(pl.gdist), pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count,
+                               pl.cand_count, ghist);
+        else
+            hipLaunchKernelGGL(select_rows_kernel<uint16_t>, dim3(nq), dim3(512), lds, s, v, pl.leaf_tables, tstride, pl.lstride, pl.rerank_k,
+                               reinterpret_cast<const uint16_t *>(pl.gdist), pl.cstride, pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count,
+                               pl.cand_count, ghist);
+    } else {
+        hipLaunchKernelGGL(scan_kernel_for(v.dim, v.words), dim3(nq), dim3(pl.scan_threads), pl.scan_lds, s, v, pl.qcodes,
+                           pl.leaf_tables, tstride, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, (void *)pl.gdist, pl.cstride,
+                           pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, ghist);
+    }
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
 }
@@ -2004,7 +2031,7 @@ extern "C" cuddle_status cuddle_scan_read_ceiling(cuddle_index *idx, const float
     auto scan_once = [&](uint32_t b) {
         hipLaunchKernelGGL(scan_kernel_for(v.dim, v.words), dim3(n_queries), dim3(pl.scan_threads), pl.scan_lds, s, v, codes_of(b),
                            tables_of(b), tstride, pl.lstride, pl.tcap, pl.rerank_k, pl.dist_cap, (void *)pl.gdist, pl.cstride,
-                           pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, (uint32_t *)nullptr, 0u);
+                           pl.sel_pos, pl.sel_key, pl.sstride, pl.sel_count, pl.cand_count, (uint32_t *)nullptr);
     };
     auto body = [&]() -> cuddle_status {
         for (uint32_t b = 0; b < n_batches; ++b) read_once(b); // one untimed round

@@ -436,6 +436,84 @@ __device__ __forceinline__ void chunked_threshold_select(WordPtr words, uint32_t
     __syncthreads();
 }
 
+// The same selection for keys in global memory (a query's row of the spill buffer): there a lane walking its own
+// run of words makes every load instruction touch 64 cache lines, so each wave owns a contiguous segment instead and
+// reads it 64 consecutive words at a time. Pass 1 counts; pass 2 ranks the keys of a step by two wave scans, and only
+// in steps that hold a selected key at all (the selection is a small part of the candidates). Keys are compared field
+// by field (any T). wtmp needs 2 * (blockDim.x / 64) u32. All threads call; contains two barriers.
+template <class DistT, class EmitFn>
+__device__ __forceinline__ void wave_threshold_select(const uint32_t *words, uint32_t C, uint32_t T, uint32_t budget,
+                                                      EmitFn emit, uint32_t *wtmp) {
+    constexpr uint32_t EPW = 4 / sizeof(DistT), BITS = 8 * sizeof(DistT), MASK = (1u << BITS) - 1;
+    const uint32_t nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t nwords = (C + EPW - 1) / EPW;
+    const uint32_t seg = (((nwords + nw - 1) / nw + 63) / 64) * 64;
+    const uint32_t wb = min(w * seg, nwords), we = min(wb + seg, nwords);
+    auto classify = [&](uint32_t j, uint32_t x, uint32_t &mlt, uint32_t &mtie) {
+        mlt = mtie = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < EPW; ++e) {
+            const uint32_t kv = (x >> (e * BITS)) & MASK;
+            const bool in = j < we && j * EPW + e < C;
+            mlt |= (in && kv < T ? 1u : 0u) << e;
+            mtie |= (in && kv == T ? 1u : 0u) << e;
+        }
+    };
+    constexpr int kSteps = 4; // loads of four steps are issued before the first is used
+    uint32_t n_lt = 0, n_tie = 0;
+    for (uint32_t j0 = wb; j0 < we; j0 += 64 * kSteps) {
+        uint32_t x[kSteps];
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u) x[u] = words[min(j0 + 64 * u + lane, nwords - 1)];
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u) {
+            uint32_t mlt, mtie;
+            classify(j0 + 64 * u + lane, x[u], mlt, mtie);
+            n_lt += __popc(mlt);
+            n_tie += __popc(mtie);
+        }
+    }
+    const uint32_t tot_lt = wave_inclusive_sum(n_lt), tot_tie = wave_inclusive_sum(n_tie);
+    if (lane == 63) {
+        wtmp[w] = tot_lt;
+        wtmp[nw + w] = tot_tie;
+    }
+    __syncthreads();
+    uint32_t lt_run = 0, tie_run = 0; // selected / tied keys before this wave's current step
+    for (uint32_t v = 0; v < w; ++v) {
+        lt_run += wtmp[v];
+        tie_run += wtmp[nw + v];
+    }
+    for (uint32_t j0 = wb; j0 < we; j0 += 64 * kSteps) {
+        uint32_t x[kSteps];
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u) x[u] = words[min(j0 + 64 * u + lane, nwords - 1)];
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u) {
+            const uint32_t j = j0 + 64 * u + lane;
+            uint32_t mlt, mtie;
+            classify(j, x[u], mlt, mtie);
+            if (__ballot((mlt | mtie) != 0) == 0) continue; // (wave-uniform)
+            const uint32_t c_lt = __popc(mlt), c_tie = __popc(mtie);
+            const uint32_t i_lt = wave_inclusive_sum(c_lt), i_tie = wave_inclusive_sum(c_tie);
+            uint32_t my_lt = lt_run + i_lt - c_lt, my_tie = tie_run + i_tie - c_tie;
+#pragma unroll
+            for (uint32_t e = 0; e < EPW; ++e) {
+                if ((mlt >> e) & 1u) {
+                    emit(j * EPW + e, my_lt + min(my_tie, budget));
+                    ++my_lt;
+                } else if ((mtie >> e) & 1u) {
+                    if (my_tie < budget) emit(j * EPW + e, my_lt + my_tie);
+                    ++my_tie;
+                }
+            }
+            lt_run += (uint32_t)__builtin_amdgcn_readlane((int)i_lt, 63);
+            tie_run += (uint32_t)__builtin_amdgcn_readlane((int)i_tie, 63);
+        }
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // exact distances in the reference's accumulation order
 // ---------------------------------------------------------------------------------------------
@@ -1142,7 +1220,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((PAIRS
 scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *tables, uint32_t tstride, uint32_t lcap,
                            uint32_t tcap, uint32_t rerank_k, uint32_t dist_cap, void *gdist_v, uint32_t gdist_stride,
                            uint32_t *sel_pos, uint32_t *sel_key, uint32_t sel_stride, uint32_t *sel_count,
-                           uint32_t *cand_count, uint32_t *ghist, uint32_t pre_dist = 0) {
+                           uint32_t *cand_count, uint32_t *ghist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const uint32_t D = ix.dim, W = ix.words;
@@ -1173,21 +1251,7 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
     typedef const __attribute__((address_space(3))) uint32_t LdsWord;
     auto body = [&](auto dist, auto dist_words) {
     // phase 1
-    if (pre_dist) {
-        // leaf_hamming_kernel has left every candidate's distance in the query's row of the spill buffer, by scan
-        // position: they move to where the selection reads them (nowhere, if that is the spill row), and are counted
-        const uint32_t *gw = reinterpret_cast<const uint32_t *>(reinterpret_cast<const DistT *>(gdist_v) + (uint64_t)q * gdist_stride);
-        constexpr uint32_t EPW = 4 / sizeof(DistT), BITS = 8 * sizeof(DistT);
-        constexpr bool copy = !std::is_same<decltype(dist), DistT *>::value; // the LDS instantiation of this body
-        LdsU32 *lw = (LdsU32 *)s.dist;
-        for (uint32_t j = tid; j < (C + EPW - 1) / EPW; j += blockDim.x) {
-            const uint32_t x = gw[j];
-            if (copy) lw[j] = x;
-#pragma unroll
-            for (uint32_t e = 0; e < EPW; ++e)
-                if (j * EPW + e < C) atomicAdd(&s.hist[(x >> (e * BITS)) & ((1u << BITS) - 1)], 1u);
-        }
-    } else if (PAIRS > 0) {
+    if (PAIRS > 0) {
         scan_tiles<PAIRS, TAIL, U, DistT>(ix, s, ntiles, dist);
     } else {
         for (uint32_t t = w; t < ntiles; t += nw) {
@@ -1245,12 +1309,16 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
     // (typed as an LDS pointer: a pointer that may be LDS or global turns every staged store into a flat instruction)
     LdsU32 *stg = (LdsU32 *)s.tiles;
     const bool stage_lds = nsel <= ((PAIRS == 1 && !TAIL) ? 3u : 2u) * scan_pad4(tcap);
-    if (stage_lds)
-        chunked_threshold_select<DistT>(
-            dist_words, C, T, budget, [&](uint32_t i, uint32_t rank) { if (rank < nsel) stg[rank] = i; }, s.wtmp);
-    else
-        chunked_threshold_select<DistT>(
-            dist_words, C, T, budget, [&](uint32_t i, uint32_t rank) { if (rank < nsel) sp[rank] = i; }, s.wtmp);
+    constexpr bool in_lds = !std::is_same<decltype(dist), DistT *>::value; // the LDS instantiation of this body
+    auto to_stage = [&](uint32_t i, uint32_t rank) { if (rank < nsel) stg[rank] = i; };
+    auto to_row = [&](uint32_t i, uint32_t rank) { if (rank < nsel) sp[rank] = i; };
+    if constexpr (in_lds) {
+        if (stage_lds) chunked_threshold_select<DistT>(dist_words, C, T, budget, to_stage, s.wtmp);
+        else chunked_threshold_select<DistT>(dist_words, C, T, budget, to_row, s.wtmp);
+    } else { // keys in the spill row: read wave by wave, coalesced
+        if (stage_lds) wave_threshold_select<DistT>(dist_words, C, T, budget, to_stage, s.wtmp);
+        else wave_threshold_select<DistT>(dist_words, C, T, budget, to_row, s.wtmp);
+    }
     if (!stage_lds) {
         __threadfence();
         __syncthreads();
@@ -1272,6 +1340,111 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
     }
 }
 
+// The selection half of scan_select_hamming_kernel for distances that are already in the queries' rows of the spill
+// buffer (leaf_hamming_kernel writes them there, by scan position): histogram, threshold, ordered selection, exactly
+// as above (select_top_candidates, hierarchical.rs:646-651 / :930-932), reading the row wave by wave. A kernel of its
+// own because it needs none of the scan's registers or LDS: 64 registers and a few KB per block, so that every query
+// of a chunk of up to 1024 is resident at once (inside the scan kernel two blocks fitted a CU and a 1000-query batch
+// ran as two rounds: 60 -> 30 us). ghist != null: histogram mode, as there. One block per query (block b takes the
+// query ranked b-th by work); dynamic LDS = select_rows_lds_bytes(dim, lcap).
+constexpr uint32_t kSelectStage = 2048; // selected scan positions staged in LDS before they are mapped (more: through sel_pos)
+inline size_t select_rows_lds_bytes(uint32_t dim, uint32_t lcap) {
+    return ((size_t)scan_pad4(dim + 2) + scan_pad4(lcap) + scan_pad4(lcap + 1) + kSelectStage + 32 + 8) * 4;
+}
+template <class DistT>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8)))
+select_rows_kernel(IndexDev ix, const uint32_t *tables, uint32_t tstride, uint32_t lcap, uint32_t rerank_k,
+                   const DistT *gdist, uint32_t gdist_stride, uint32_t *sel_pos, uint32_t *sel_key, uint32_t sel_stride,
+                   uint32_t *sel_count, uint32_t *cand_count, uint32_t *ghist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem), *lbeg = hist + scan_pad4(ix.dim + 2), *lscan = lbeg + scan_pad4(lcap);
+    uint32_t *stage = lscan + scan_pad4(lcap + 1), *wtmp = stage + kSelectStage, *misc = wtmp + 32;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, D = ix.dim;
+    const uint32_t *tb = tables + (uint64_t)blockIdx.x * 4 * tstride;
+    for (uint32_t i = tid; i < D + 2; i += blockDim.x) hist[i] = 0;
+    for (uint32_t t = tid; t <= lcap; t += blockDim.x) {
+        lscan[t] = tb[tstride + t];
+        if (t < lcap) lbeg[t] = tb[t];
+    }
+    if (tid < 2) misc[4 + tid] = tb[tstride - 2 + tid];
+    __syncthreads();
+    const uint32_t q = misc[4], nl = min(misc[5], lcap), C = lscan[nl];
+    if (tid == 0) cand_count[q] = C;
+    if (C == 0) {
+        if (tid == 0) sel_count[q] = 0;
+        if (ghist)
+            for (uint32_t i = tid; i <= D; i += blockDim.x) ghist[(uint64_t)q * (D + 1) + i] = 0;
+        return;
+    }
+    const DistT *row = gdist + (uint64_t)q * gdist_stride;
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(row);
+    constexpr uint32_t EPW = 4 / sizeof(DistT), BITS = 8 * sizeof(DistT), MASK = (1u << BITS) - 1;
+    const uint32_t nwords = (C + EPW - 1) / EPW;
+    for (uint32_t j0 = tid; j0 < nwords; j0 += 4 * blockDim.x) { // four loads in flight per lane
+        uint32_t x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = words[min(j0 + u * blockDim.x, nwords - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t j = j0 + u * blockDim.x;
+#pragma unroll
+            for (uint32_t e = 0; e < EPW; ++e)
+                if (j < nwords && j * EPW + e < C) atomicAdd(&hist[(x[u] >> (e * BITS)) & MASK], 1u);
+        }
+    }
+    __syncthreads();
+    if (ghist) {
+        for (uint32_t i = tid; i <= D; i += blockDim.x) ghist[(uint64_t)q * (D + 1) + i] = hist[i];
+        return;
+    }
+    uint32_t T, budget;
+    if (C <= rerank_k) {
+        T = D + 1; // every candidate is < T
+        budget = 0;
+    } else {
+        if (w == 0) {
+            uint32_t carry = 0;
+            bool done = false;
+            for (uint32_t b0 = 0; b0 <= D && !done; b0 += 64) {
+                const uint32_t b = b0 + lane, v = b <= D ? hist[b] : 0;
+                const uint32_t incl = wave_inclusive_sum(v) + carry;
+                const uint64_t hit = __ballot(incl >= rerank_k);
+                if (hit) {
+                    const uint32_t first = __ffsll((unsigned long long)hit) - 1;
+                    const uint32_t incl_f = (uint32_t)__builtin_amdgcn_readlane((int)incl, first), v_f = (uint32_t)__builtin_amdgcn_readlane((int)v, first);
+                    if (lane == 0) {
+                        misc[0] = b0 + first;
+                        misc[1] = rerank_k - (incl_f - v_f);
+                    }
+                    done = true;
+                }
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+        }
+        __syncthreads();
+        T = misc[0];
+        budget = misc[1];
+    }
+    uint32_t *sp = sel_pos + (uint64_t)q * sel_stride, *sk = sel_key + (uint64_t)q * sel_stride;
+    const uint32_t nsel = min(min(C, rerank_k), sel_stride);
+    const bool in_lds = nsel <= kSelectStage;
+    if (in_lds)
+        wave_threshold_select<DistT>(words, C, T, budget, [&](uint32_t i, uint32_t rank) { if (rank < nsel) stage[rank] = i; }, wtmp);
+    else
+        wave_threshold_select<DistT>(words, C, T, budget, [&](uint32_t i, uint32_t rank) { if (rank < nsel) sp[rank] = i; }, wtmp);
+    if (!in_lds) {
+        __threadfence();
+        __syncthreads();
+    }
+    for (uint32_t r = tid; r < nsel; r += blockDim.x) {
+        const uint32_t i = in_lds ? stage[r] : __hip_atomic_load(sp + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t sl = scan_slot_of(lscan, nl, i);
+        sp[r] = lbeg[sl] + (i - lscan[sl]);
+        sk[r] = row[i];
+    }
+    if (tid == 0) sel_count[q] = nsel;
+}
+
 // popcount(x) + acc in one instruction (the compiler otherwise splits it into a count and a three-way add).
 __device__ __forceinline__ void popc_acc(uint32_t &acc, uint32_t x) {
     asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x));
@@ -1289,59 +1462,138 @@ __global__ void leaf_pair_fill_kernel(const uint2 *info, const uint32_t *node_of
     sorted[poff[node_of[at]] + place_of[at]] = v;
 }
 
+// Work of a leaf item in 256 classes, heaviest = class 0: pairs x passes of 128 vectors over the leaf.
+constexpr uint32_t kWorkBins = 256;
+__device__ __forceinline__ uint32_t item_work_bin(uint32_t np, uint32_t nv) {
+    return (kWorkBins - 1) - min(np * ((nv + 127) >> 7), kWorkBins - 1);
+}
+
+// Launch order of leaf_hamming_kernel's work items, heaviest first (work = pairs x 128-vector passes over the leaf): a
+// launch ends with its last block, and an item of 64 pairs that starts when most of the grid is done runs on alone
+// for as long as the whole rest took (measured: 97 -> 68 us for 10 000 items of 1 to 64 pairs). A counting sort by
+// work class: pair_scan_kernel has counted the items per class into bins[0 .. 256); every block sums the classes
+// before each one for itself, and an item takes the next free place of its class (bins[256 ..], zero at launch).
+// Order inside a class is immaterial. grid = ceil(max items / 256), block 256.
+__global__ void __launch_bounds__(256)
+item_scatter_kernel(IndexDev ix, const uint32_t *n_items, const uint4 *items, uint32_t *bins, uint32_t *order) {
+    __shared__ uint32_t start[kWorkBins];
+    const uint32_t tid = threadIdx.x, n = *n_items;
+    if (blockIdx.x * 256 >= n) return;
+    {
+        const uint32_t h = bins[tid], incl = wave_inclusive_sum(h);
+        __shared__ uint32_t wsum[4];
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t v = 0; v < (tid >> 6); ++v) before += wsum[v];
+        start[tid] = before + incl - h;
+    }
+    __syncthreads();
+    // places inside a class: by LDS counter within the block, one global add per class and block for the block's base
+    __shared__ uint32_t lcnt[kWorkBins], gbase[kWorkBins];
+    lcnt[tid] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256 + tid;
+    uint32_t b = 0, local = 0;
+    if (i < n) {
+        const uint4 it = items[i];
+        b = item_work_bin(it.z, ix.vec_off[it.x + 1] - ix.vec_off[it.x]);
+        local = atomicAdd(&lcnt[b], 1u);
+    }
+    __syncthreads();
+    if (lcnt[tid]) gbase[tid] = atomicAdd(&bins[kWorkBins + tid], lcnt[tid]);
+    __syncthreads();
+    if (i < n) order[start[b] + gbase[b] + local] = i;
+}
+
 // The Hamming scan leaf by leaf, for batches in which a leaf is reached by several queries: one block per work item
 // (leaf, up to 64 of the queries that reach it; pair_scan_kernel cuts the items; blocks past the last item exit).
 // The item's query codes are staged in LDS once; each of the block's two waves then takes 64-vector tiles of the
 // leaf, a lane keeping the code of one vector in registers (the planar layout: one coalesced 16-byte load per pair
 // of words) while the queries go by, their codes read from LDS at an address that is the same for every lane.
 // Every (query, vector) distance goes to the query's row of the spill buffer at the candidate's scan position, where
-// scan_select_hamming_kernel (pre_dist) picks it up. The leaf's code bytes are read once per item instead of once per
+// select_rows_kernel picks it up. The leaf's code bytes are read once per item instead of once per
 // query: compute_hamming_distances (hierarchical.rs:591-614) for all of collect_leaf_candidates' pairs (:618-641),
 // grouped by leaf. (Measured on 1000 x 232 leaves of 960-d codes, 94 us: two vectors per lane, two queries per turn
 // with explicit counting adds, and items cut in two for a shorter tail were all no faster.)
 template <class DistT, int PAIRS, bool TAIL>
 __global__ void __launch_bounds__(128)
-leaf_hamming_kernel(IndexDev ix, const uint32_t *n_items, const uint4 *items, const uint2 *sorted,
+leaf_hamming_kernel(IndexDev ix, const uint32_t *n_items, const uint4 *items, const uint32_t *order, const uint2 *sorted,
                     const uint64_t *__restrict__ qcodes, DistT *gdist, uint32_t gdist_stride) {
     constexpr uint32_t W = 2 * PAIRS + (TAIL ? 1 : 0), WP = 2 * PAIRS + (TAIL ? 2 : 0); // LDS rows of whole 16-byte pieces
     __shared__ __attribute__((aligned(16))) uint64_t sq[64 * WP];
     __shared__ uint2 spair[64];
     if (blockIdx.x >= *n_items) return;
-    const uint4 it = items[blockIdx.x]; // (leaf, first pair, pairs, -)
+    CUDDLE_STAMP(10, 0);
+    const uint4 it = items[order ? order[blockIdx.x] : blockIdx.x]; // (leaf, first pair, pairs, -); order: heaviest first
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t leaf = it.x, first = it.y, np = it.z;
     if (tid < np) spair[tid] = sorted[first + tid];
     const uint32_t beg = ix.vec_off[leaf], n = ix.vec_off[leaf + 1] - beg;
     const uint4 *planes = ix.codes + ix.code_off[leaf];
+    // the wave's first tile of the leaf is requested before the queries are staged: its loads need nothing the
+    // staging produces, and a block's time is mostly the dependent trips to memory it makes
+    uint4 c[PAIRS > 0 ? PAIRS : 1];
+    uint2 ct = make_uint2(0, 0);
+    auto request = [&](uint32_t m0) {
+        const uint32_t ii = min(m0 + lane, n - 1);
+#pragma unroll
+        for (int p = 0; p < PAIRS; ++p) c[p] = planes[(uint64_t)p * n + ii];
+        if (TAIL) ct = reinterpret_cast<const uint2 *>(planes + (uint64_t)PAIRS * n)[ii];
+    };
+    if (64 * w < n) request(64 * w);
     __syncthreads();
+    CUDDLE_STAMP(10, 1);
     for (uint32_t t = tid; t < np * WP; t += 128) {
         const uint32_t p = t / WP, u = t % WP;
         sq[t] = u < W ? qcodes[(uint64_t)spair[p].x * W + u] : 0ull;
     }
     __syncthreads();
-    typedef const __attribute__((address_space(3))) uint64_t LdsU64;
-    LdsU64 *lq = (LdsU64 *)sq;
+    CUDDLE_STAMP(10, 2);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) u32x4 LdsU4;
+    LdsU4 *lq = (LdsU4 *)sq;
     for (uint32_t m0 = 64 * w; m0 < n; m0 += 128) {
-        const uint32_t i = m0 + lane, ii = min(i, n - 1);
-        uint4 c[PAIRS > 0 ? PAIRS : 1];
-        uint2 ct = make_uint2(0, 0);
-#pragma unroll
-        for (int p = 0; p < PAIRS; ++p) c[p] = planes[(uint64_t)p * n + ii];
-        if (TAIL) ct = reinterpret_cast<const uint2 *>(planes + (uint64_t)PAIRS * n)[ii];
-#pragma unroll 2
-        for (uint32_t p = 0; p < np; ++p) {
-            LdsU64 *qw = lq + p * WP;
-            uint32_t h = 0;
+        const uint32_t i = m0 + lane;
+        if (m0 != 64 * w) request(m0);
+        // two queries per turn, written out (the row addresses below come from wave-uniform reads, which the compiler
+        // will not unroll across); an odd last turn computes its one query twice and stores it once
+        for (uint32_t p = 0; p < np; p += 2) {
+            const uint32_t p1 = min(p + 1, np - 1);
+            LdsU4 *qa = lq + p * (WP / 2), *qb = lq + p1 * (WP / 2);
+            // one chain of popcount-accumulates per query (left to itself the compiler counts every 64-bit word apart
+            // and adds the counts: five instructions per word instead of four)
+            uint32_t ha = 0, hb = 0;
 #pragma unroll
             for (int u = 0; u < PAIRS; ++u) {
-                const uint64_t a = ((uint64_t)c[u].y << 32) | c[u].x, b = ((uint64_t)c[u].w << 32) | c[u].z;
-                h += __popcll(a ^ qw[2 * u]) + __popcll(b ^ qw[2 * u + 1]);
+                const u32x4 va = qa[u], vb = qb[u];
+                popc_acc(ha, c[u].x ^ va.x);
+                popc_acc(hb, c[u].x ^ vb.x);
+                popc_acc(ha, c[u].y ^ va.y);
+                popc_acc(hb, c[u].y ^ vb.y);
+                popc_acc(ha, c[u].z ^ va.z);
+                popc_acc(hb, c[u].z ^ vb.z);
+                popc_acc(ha, c[u].w ^ va.w);
+                popc_acc(hb, c[u].w ^ vb.w);
             }
-            if (TAIL) h += __popcll((((uint64_t)ct.y << 32) | ct.x) ^ qw[2 * PAIRS]);
-            const uint2 pr = spair[p];
-            if (i < n) gdist[(uint64_t)pr.x * gdist_stride + pr.y + i] = (DistT)h;
+            if (TAIL) {
+                const u32x4 va = qa[PAIRS], vb = qb[PAIRS];
+                popc_acc(ha, ct.x ^ va.x);
+                popc_acc(hb, ct.x ^ vb.x);
+                popc_acc(ha, ct.y ^ va.y);
+                popc_acc(hb, ct.y ^ vb.y);
+            }
+            // a pair is the same for every lane: its row's address is scalar arithmetic, the lane adds its own element
+            const uint2 pa = spair[p], pb = spair[p1];
+            DistT *ra = gdist + (uint64_t)__builtin_amdgcn_readfirstlane(pa.x) * gdist_stride + __builtin_amdgcn_readfirstlane(pa.y);
+            DistT *rb = gdist + (uint64_t)__builtin_amdgcn_readfirstlane(pb.x) * gdist_stride + __builtin_amdgcn_readfirstlane(pb.y);
+            if (i < n) {
+                ra[i] = (DistT)ha;
+                if (p1 != p) rb[i] = (DistT)hb;
+            }
         }
     }
+    CUDDLE_STAMP(10, 3);
 }
 
 // Measuring aid: the memory side of scan_select_hamming_kernel and nothing else. Same grid, block, LDS size and

@@ -683,8 +683,10 @@ pair_block_scan_kernel(uint32_t *bsum, uint32_t nb, uint32_t n, uint32_t *poff, 
 
 __global__ void __launch_bounds__(256)
 pair_scan_kernel(const uint32_t *cnt, uint32_t n, const uint32_t *bsum, uint32_t nb, uint32_t *poff, uint32_t *ioff,
-                 uint4 *items, const uint2 *child_rows) {
+                 uint4 *items, const uint2 *child_rows, uint32_t *work_bins = nullptr, const uint32_t *vec_off = nullptr) {
     __shared__ uint32_t lds8[8];
+    __shared__ uint32_t wb[kWorkBins]; // this block's items per work class (one global add per class and block)
+    if (work_bins) wb[threadIdx.x] = 0; // (256 threads, 256 classes; visible after the scan's barrier)
     const uint32_t base = blockIdx.x * kPairScanChunk + threadIdx.x * 4;
     uint32_t c4[4], ap = 0, ai = 0;
     for (uint32_t k = 0; k < 4; ++k) {
@@ -741,13 +743,21 @@ pair_scan_kernel(const uint32_t *cnt, uint32_t n, const uint32_t *bsum, uint32_t
         ioff[i] = ri;
         if (ni) {
             const uint2 cr = child_rows ? child_rows[i] : make_uint2(0u, 0u);
+            // work_bins != null (parents are leaves, vec_off their vector ranges): the items are also counted by work,
+            // for item_scatter_kernel to put them in heaviest-first order
+            const uint32_t nv = work_bins ? vec_off[i + 1] - vec_off[i] : 0u;
             for (uint32_t t = 0; t < ni; ++t) {
                 const uint32_t first = rp + t * kGroupPairs, np = min((uint32_t)kGroupPairs, c - t * kGroupPairs);
                 items[ri + t] = child_rows ? make_uint4(first, np, cr.x, cr.y) : make_uint4(i, first, np, 0u);
+                if (work_bins) atomicAdd(&wb[item_work_bin(np, nv)], 1u);
             }
         }
         rp += c;
         ri += ni;
+    }
+    if (work_bins) {
+        __syncthreads();
+        if (wb[threadIdx.x]) atomicAdd(&work_bins[threadIdx.x], wb[threadIdx.x]);
     }
 }
 
