@@ -574,11 +574,11 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
     code_bytes = (4 * ((cfg["dim"] + 31) // 32) + 8) if rabitq else 8 * ((cfg["dim"] + 63) // 64)
     scan_kernel = "scan_select_rabitq_kernel" if rabitq else "scan_select_hamming_kernel"
     # binary codes of 512 bits and more, batches that reach a leaf several times over: the scan goes leaf by leaf
-    # (leaf_hamming_kernel reads a leaf's codes once per 64 queries, scan_select_hamming_kernel selects from the
-    # distances it hands over); the scan stage is then those two launches
+    # (leaf_hamming_kernel reads a leaf's codes once per 64 queries, select_rows_kernel selects from the distances it
+    # hands over; item_scatter_kernel, where it runs, orders the work items); the scan stage is then those launches
     scan_mode = dev_index.scan_mode(nq, probes) if not rabitq else "per_query"
     if scan_mode == "leaf_by_leaf":
-        scan_kernel = "leaf_hamming_kernel + scan_select_hamming_kernel"
+        scan_kernel = "leaf_hamming_kernel + select_rows_kernel"
     scan_bytes = stats["vectors_scanned"] * code_bytes           # algorithmic bytes of one launch (this rank, last step)
     rerank_bytes = stats["vectors_reranked"] * 4 * cfg["dim"]
     n_timed = max(stage["searches"], 1)
@@ -590,6 +590,8 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
         pmc = json.load(open(pmc_path))
         parts = [pmc["kernels"].get(kn.strip(), {}).get("traffic_bytes_per_launch") for kn in scan_kernel.split("+")]
         traffic = sum(parts) if all(p is not None for p in parts) else None
+        if traffic is not None and scan_mode == "leaf_by_leaf":  # (runs only where items differ enough in size to be ordered)
+            traffic += pmc["kernels"].get("item_scatter_kernel", {}).get("traffic_bytes_per_launch") or 0.0
         traffic_src = os.path.relpath(pmc_path, ROOT)
     code_array = dev_index_codes_bytes = (n_total // world) * code_bytes
     fits_l3 = code_array <= (256 << 20)
@@ -606,7 +608,7 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
                           "hierarchical.rs:591-641) over the time of the two launches that replace those reads - a leaf's codes are "
                           "fetched once per 64 queries that reach it, so the figure may pass what memory could deliver per query "
                           "(frac > 1) and `traffic` is far below the algorithmic bytes; what limits the launches is integer issue "
-                          "(one xor and one counting add per 32 code bits and pair) and, for the selection, LDS; "
+                          "(one xor and one counting add per 32 code bits and pair); the selection reads the distances back from the spill rows; "
                           if scan_mode == "leaf_by_leaf" else "") +
                          ("the whole code array fits the 256 MiB Infinity Cache: achieved is on-die cache bandwidth as much as "
                           "HBM bandwidth (see roofline_hbm_resident for the same kernel on a code array that does not fit); "
