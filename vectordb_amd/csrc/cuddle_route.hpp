@@ -685,6 +685,7 @@ __global__ void __launch_bounds__(256)
 pair_scan_kernel(const uint32_t *cnt, uint32_t n, const uint32_t *bsum, uint32_t nb, uint32_t *poff, uint32_t *ioff,
                  uint4 *items, const uint2 *child_rows, uint32_t *work_bins = nullptr, const uint32_t *vec_off = nullptr) {
     __shared__ uint32_t lds8[8];
+    static_assert(kWorkBins == 256, "one work class per thread of the block");
     __shared__ uint32_t wb[kWorkBins]; // this block's items per work class (one global add per class and block)
     if (work_bins) wb[threadIdx.x] = 0; // (256 threads, 256 classes; visible after the scan's barrier)
     const uint32_t base = blockIdx.x * kPairScanChunk + threadIdx.x * 4;
