@@ -178,7 +178,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // that every key shares (found from the block's min and max) cost nothing; each pass over the rest
 // is one counting sweep with LDS atomics and ONE barrier: each wave then scans the 256 counters itself.
 // hist: 4 * 256 u32 of LDS, zeroed here; wred: 2 * (THREADS / 64) u32. All threads call.
-template <int THREADS, int KPT>
+// UPPER: stop at the first digit whose bucket holds at most four keys and return the largest key that bucket can
+// hold - an upper bound of the want-th smallest key that at least `want` and at most `want` + 3 keys reach, for
+// callers that only need a cut (budget is not set).
+template <int THREADS, int KPT, bool UPPER = false>
 __device__ __forceinline__ uint32_t reg_radix_select(const uint32_t (&keys)[KPT], uint32_t n, uint32_t want, uint32_t *hist,
                                                      uint32_t *wred, uint32_t &budget) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -226,13 +229,16 @@ __device__ __forceinline__ uint32_t reg_radix_select(const uint32_t (&keys)[KPT]
         const uint32_t incl = wave_inclusive_sum(s4);
         const uint64_t hit = __ballot(incl >= want);
         const uint32_t first = hit ? (uint32_t)__ffsll((unsigned long long)hit) - 1 : 63u;
-        uint32_t cum = incl - s4, b = 4 * lane;
-        if (cum + h0 < want) { cum += h0; ++b;
-            if (cum + h1 < want) { cum += h1; ++b;
-                if (cum + h2 < want) { cum += h2; ++b; } } }
+        uint32_t cum = incl - s4, b = 4 * lane, hb = h0;
+        if (cum + h0 < want) { cum += h0; ++b; hb = h1;
+            if (cum + h1 < want) { cum += h1; ++b; hb = h2;
+                if (cum + h2 < want) { cum += h2; ++b; hb = h3; } } }
         prefix |= (uint32_t)__builtin_amdgcn_readlane((int)b, first) << shift;
         want -= (uint32_t)__builtin_amdgcn_readlane((int)cum, first);
         rem = shift;
+        // UPPER: the bucket's upper edge will do once the bucket holds only a few keys (they are all the cut lets in
+        // beyond the want-th)
+        if (UPPER && (uint32_t)__builtin_amdgcn_readlane((int)hb, first) <= 4) return prefix | (rem ? (1u << rem) - 1 : 0u);
     }
     budget = want;
     return prefix;
@@ -1716,7 +1722,9 @@ route_prefilter_reg_kernel(const float *fdist, uint32_t fstride, uint32_t n, uin
         for (int t = 1; t < KPT; ++t) lmin[0] = min(lmin[0], keys[t]);
         uint32_t b0;
         CUDDLE_STAMP(8, 1);
-        const uint32_t T0 = reg_radix_select<THREADS, 1>(lmin, min(n, (uint32_t)THREADS), kc, hist, wred, b0);
+        // (a cut, not the exact kc-th minimum: the selection stops at the digit that leaves at most four minima in its
+        // bucket and takes the bucket's upper edge)
+        const uint32_t T0 = reg_radix_select<THREADS, 1, true>(lmin, min(n, (uint32_t)THREADS), kc, hist, wred, b0);
         CUDDLE_STAMP(8, 2);
         if (lmin[0] <= T0) {
 #pragma unroll
