@@ -1388,15 +1388,25 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         const uint32_t small_gx = std::max<uint32_t>(2, std::min<uint32_t>(8, 8192 / std::max<uint32_t>(nq, 1)));
         const uint32_t dist_gx = (use_gemm || grouped_filter) ? 1 : grouped ? 4
                                  : std::min<uint32_t>((bound + 63) / 64, (shared || (flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY)) ? 64 : small_gx);
-        if (!keep_all)
+        // after a filter path the exact kernels serve only the queries the filter left (normally none): one block per
+        // query would compute their distances, so the selection kernel does it itself and the launch is saved
+        const bool fuse_dist = !keep_all && (use_gemm || grouped_filter) && bound <= 512 * 32 &&
+                               route_select_reg_lds_bytes(scap, v.dim) <= 150 * 1024;
+        FusedDist fd_args;
+        if (fuse_dist) {
+            fd_args.queries = dq;
+            fd_args.qnorm = pl.qnorm;
+            fd_args.fdist = pl.fdist;
+        }
+        if (!keep_all && !fuse_dist)
             hipLaunchKernelGGL(route_dist_kernel, dim3(dist_gx, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                pl.frontier[cur], pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, only, pl.qnorm);
         const uint32_t *sel_only = (grouped && !grouped_filter) ? nullptr : only; // after the exact grouped path every query still selects here
 #define CUDDLE_SELECT_REG(T, K)                                                                                              \
-    hipLaunchKernelGGL((route_select_reg_kernel<T, K>), dim3(nq), dim3(T), route_select_reg_lds_bytes(scap), s, v, pl.frontier[cur], \
-                       pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, scap,                                    \
+    hipLaunchKernelGGL((route_select_reg_kernel<T, K>), dim3(nq), dim3(T), route_select_reg_lds_bytes(scap, fuse_dist ? v.dim : 0), s, v, \
+                       pl.frontier[cur], pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, scap,                  \
                        next_shared ? nullptr : pl.frontier[cur ^ 1], pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,       \
-                       sel_only, po)
+                       sel_only, po, fd_args)
         // small blocks, as few keys per thread as the level's bound allows: a block's time is mostly
         // latency (loads, barriers), so what counts is how many of them are in flight
         if (!keep_all && bound <= 256 * 8)

@@ -391,24 +391,16 @@ quantize_init_kernel(const float *v, uint64_t n, uint32_t dim, uint32_t words, f
 // query's frontier is the list shared_fr[0..shared_n) (frontier / fcount are not read).
 // grid = (gx, nq) with any gx >= 1 (blocks stride over the nodes), block = 256: one 4-lane group
 // per (query, node).
-__global__ void __launch_bounds__(256)
-route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, uint32_t fstride,
-                  const uint32_t *fcount, const uint32_t *shared_fr, uint32_t shared_n, float *fdist, uint32_t probes,
-                  uint32_t stats_variant, const uint32_t *only_flag, const float *qnorm) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *qs = reinterpret_cast<float *>(smem);
-    const uint32_t q = blockIdx.y;
-    if (only_flag && !only_flag[q]) return;
-    const uint32_t n = shared_fr ? shared_n : fcount[q];
-    if (!stats_variant && n <= probes) return;
+// The work of one block of route_dist_kernel for query q: block bx of gx over the frontier's nodes. qs: dim floats of
+// LDS. All threads of the block call (one barrier inside).
+__device__ __forceinline__ void route_dist_block(const IndexDev &ix, float *qs, const float *qg, const uint32_t *fr, float *fd,
+                                                 uint32_t n, uint32_t probes, uint32_t stats_variant, float qnorm_q, uint32_t bx,
+                                                 uint32_t gx) {
     const uint32_t D = ix.dim;
     const bool small = !stats_variant && n >= 4 && n <= 100;
-    if (small ? (blockIdx.x != 0) : (blockIdx.x * 64 >= n)) return;
-    const float *qg = queries + (uint64_t)q * D;
+    if (small ? (bx != 0) : (bx * (blockDim.x >> 2) >= n)) return; // (block-uniform)
     for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) qs[i] = qg[i];
     __syncthreads();
-    const uint32_t *fr = shared_fr ? shared_fr : frontier + (uint64_t)q * fstride;
-    float *fd = fdist + (uint64_t)q * fstride;
     if (small) {
         uint32_t j = threadIdx.x;
         if (j < n) {
@@ -417,20 +409,41 @@ route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, u
         }
         return;
     }
-    const uint32_t sub = threadIdx.x & 3;
+    const uint32_t sub = threadIdx.x & 3, groups = blockDim.x >> 2;
     const bool vec = (D & 3) == 0;
-    for (uint32_t j0 = blockIdx.x * 64; j0 < n; j0 += gridDim.x * 64) { // block-uniform trip count
+    for (uint32_t j0 = bx * groups; j0 < n; j0 += gx * groups) { // block-uniform trip count
         const uint32_t j = j0 + (threadIdx.x >> 2);
         const bool act = j < n;
         const uint32_t node = fr[act ? j : 0];
-        float d = distance_group4_qn(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, vec,
-                                     ix.metric == kMetricCosine ? qnorm[q] : 0.f);
+        float d = distance_group4_qn(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, vec, qnorm_q);
         if (act && sub == 0) fd[j] = d;
     }
 }
 
-inline size_t route_select_reg_lds_bytes(uint32_t scap) { // route_select_reg_kernel: four radix histograms
-    return (size_t)scap * 8 + 4 * 256 * 4 + 32 * 4 + 8 * 4 + 4 * ((size_t)scap + 1) * 4 + 16;
+__global__ void __launch_bounds__(256)
+route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, uint32_t fstride,
+                  const uint32_t *fcount, const uint32_t *shared_fr, uint32_t shared_n, float *fdist, uint32_t probes,
+                  uint32_t stats_variant, const uint32_t *only_flag, const float *qnorm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t q = blockIdx.y;
+    if (only_flag && !only_flag[q]) return;
+    const uint32_t n = shared_fr ? shared_n : fcount[q];
+    if (!stats_variant && n <= probes) return;
+    route_dist_block(ix, reinterpret_cast<float *>(smem), queries + (uint64_t)q * ix.dim,
+                     shared_fr ? shared_fr : frontier + (uint64_t)q * fstride, fdist + (uint64_t)q * fstride, n, probes,
+                     stats_variant, ix.metric == kMetricCosine ? qnorm[q] : 0.f, blockIdx.x, gridDim.x);
+}
+
+// What route_select_reg_kernel needs to evaluate a query's exact distances itself before it selects (the two kernels
+// that serve queries the matrix-core filter could not decide, as one launch): null queries = distances are in fdist.
+struct FusedDist {
+    const float *queries = nullptr;
+    const float *qnorm = nullptr;
+    float *fdist = nullptr;
+};
+
+inline size_t route_select_reg_lds_bytes(uint32_t scap, uint32_t fused_dim = 0) { // route_select_reg_kernel: four radix histograms (+ the query)
+    return (size_t)scap * 8 + 4 * 256 * 4 + 32 * 4 + 8 * 4 + 4 * ((size_t)scap + 1) * 4 + 16 + ((size_t)fused_dim + 4) * 4;
 }
 
 inline size_t route_select_lds_bytes(uint32_t scap) {
@@ -512,7 +525,8 @@ __global__ void __launch_bounds__(THREADS)
 route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride, const uint32_t *fcount,
                         const uint32_t *shared_fr, uint32_t shared_n, const float *fdist, uint32_t probes,
                         uint32_t stats_variant, uint32_t scap, uint32_t *next_frontier, uint32_t *next_fcount,
-                        uint32_t *leaves, uint32_t lstride, uint32_t *lcount, const uint32_t *only_flag, PairOut po) {
+                        uint32_t *leaves, uint32_t lstride, uint32_t *lcount, const uint32_t *only_flag, PairOut po,
+                        FusedDist fused = FusedDist()) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *skeys = reinterpret_cast<uint64_t *>(smem);                 // [scap]
     uint32_t *hist = reinterpret_cast<uint32_t *>(skeys + scap);         // [4 * 256]
@@ -523,6 +537,16 @@ route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride,
     if (only_flag && !only_flag[q]) return;
     const uint32_t n = shared_fr ? shared_n : fcount[q];
     const uint32_t tid = threadIdx.x;
+    if (fused.queries && (stats_variant || n > probes)) {
+        // the query's exact distances first (route_dist_kernel's work for one block per query), then the selection reads
+        // them back: written and read by this block, a barrier apart
+        float *qs = reinterpret_cast<float *>(reinterpret_cast<uintptr_t>(xs + 4 * ((size_t)scap + 1) + 3) & ~(uintptr_t)15);
+        route_dist_block(ix, qs, fused.queries + (uint64_t)q * ix.dim, shared_fr ? shared_fr : frontier + (uint64_t)q * fstride,
+                         fused.fdist + (uint64_t)q * fstride, n, probes, stats_variant,
+                         ix.metric == kMetricCosine ? fused.qnorm[q] : 0.f, 0, 1);
+        __threadfence_block();
+        __syncthreads();
+    }
     if (n == 0) {
         if (tid == 0 && next_frontier) next_fcount[q] = 0;
         if (po.info) {
