@@ -1332,6 +1332,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         // expansion also records its (query, chosen node) pairs, grouped by node for that level.
         PairOut po;
         bool group_next = false, seg_next = false;
+        const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound && finish_fits(g.n);
+        uint32_t *zero_cnt = nullptr; // the next level's pair counters, cleared by this level's refinement kernel when it has one
         if (l + 1 < ix->n_levels && !next_shared && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && pl.fstride <= (1u << kPairOffBits)) {
             // grouping has a fixed cost (pair sort, one block per 64 pairs): worth it when a query's
             // next frontier is expected to be wide, i.e. chosen nodes x mean fan-out of this level
@@ -1346,7 +1348,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 // need a frontier position's node for a few hundred positions per query, not the frontier itself
                 seg_next = !stats && ix->lvl[l + 1].n && bound_next <= 512 * 32 && !no_filter && finish_fits(bound_next);
                 if (seg_next) po.seg = pl.seg[cur ^ 1];
-                HIP_TRY(hipMemsetAsync(pl.grp_cnt, 0, ((size_t)ix->level_width[l] + 1) * 4, s));
+                if (use_gemm) zero_cnt = pl.grp_cnt;
+                else HIP_TRY(hipMemsetAsync(pl.grp_cnt, 0, ((size_t)ix->level_width[l] + 1) * 4, s));
             }
         }
         if (grouped_finish) {
@@ -1359,7 +1362,6 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 hipLaunchKernelGGL(route_materialise_kernel, dim3(nq), dim3(256), seg_stride(pl.probes) * 4, s, v, pl.seg[cur], pl.probes,
                                    pl.rflag, pl.small_flag, pl.frontier[cur], pl.fstride, pl.fcount[cur]);
         }
-        const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound && finish_fits(g.n);
         if (use_gemm) {
             const bool half = half_on(l);
             used_half |= half;
@@ -1371,7 +1373,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 hipLaunchKernelGGL(route_prefilter_kernel, dim3(nq), dim3(256), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,
                                    pl.kc_cap, pl.rc_max);
             hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
-                               g.nodes, pl.rc_pos, pl.kc_cap, kc, pl.rc_dist, pl.qnorm);
+                               g.nodes, pl.rc_pos, pl.kc_cap, kc, pl.rc_dist, pl.qnorm, 0u, (const uint32_t *)nullptr,
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, zero_cnt, ix->level_width[l] + 1);
             hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(kc), pl.probes), s,
                                v, g.nodes, n, pl.rc_pos, pl.rc_dist, pl.kc_cap, kc, pl.rc_max, pl.qsq, g.max_sqn, pl.probes,
                                pl.frontier[cur ^ 1], pl.fstride, pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,

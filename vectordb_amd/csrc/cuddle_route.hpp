@@ -1804,11 +1804,15 @@ __global__ void __launch_bounds__(256)
 route_refine_kernel(IndexDev ix, const float *queries, const uint32_t *level_nodes, const uint32_t *cand_pos,
                     uint32_t cstride, uint32_t kc, float *cand_dist, const float *qnorm, uint32_t fstride = 0,
                     const uint32_t *skip = nullptr, const uint32_t *cand_cnt = nullptr, const uint32_t *seg = nullptr,
-                    uint32_t pstride = 0) {
+                    uint32_t pstride = 0, uint32_t *zero = nullptr, uint32_t n_zero = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);
     uint32_t *st = reinterpret_cast<uint32_t *>(qs + ((ix.dim + 3) & ~3u)); // the query's segment table (seg != null)
     const uint32_t q = blockIdx.y, D = ix.dim;
+    if (zero) { // the pair counters the level's finish kernel fills next (instead of a memset launch of their own)
+        const uint32_t nt = gridDim.x * gridDim.y * blockDim.x;
+        for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n_zero; i += nt) zero[i] = 0;
+    }
     if (skip && skip[q]) return;
     if (cand_cnt) { // per-query frontiers: level_nodes is the array of frontiers, fstride nodes per query
         kc = cand_cnt[q];
