@@ -1331,7 +1331,10 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         // Will the next level evaluate per-query frontiers wider than probes? Then this level's
         // expansion also records its (query, chosen node) pairs, grouped by node for that level.
         PairOut po;
-        bool group_next = false, seg_next = false;
+        bool group_next = false, seg_next = false, materialise_pending = false;
+        // (the selection kernel can take over the exact distances, and the frontiers, of the queries a filter path leaves)
+        const bool fuse_ok = bound <= 512 * 32 && route_select_reg_lds_bytes(scap, v.dim) <= 150 * 1024 &&
+                             (size_t)seg_stride(pl.probes) * 4 <= (size_t)scap * 8 + 4 * 256 * 4;
         const bool use_gemm = shared && !keep_all && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && g.n && g.n == bound && finish_fits(g.n);
         uint32_t *zero_cnt = nullptr; // the next level's pair counters, cleared by this level's refinement kernel when it has one
         if (l + 1 < ix->n_levels && !next_shared && !(flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY) && pl.fstride <= (1u << kPairOffBits)) {
@@ -1358,7 +1361,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                                pl.probes, pl.frontier[cur ^ 1], pl.fstride, pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,
                                pl.rflag, &ix->d_stats->fallbacks, po, pl.fcount[cur], pl.small_flag, pl.rc_cnt,
                                have_seg ? pl.seg[cur] : nullptr, grouped_half ? 1u : 0u, grouped_half ? ix->d_half_fb + l : nullptr);
-            if (have_seg) // queries that failed the proof go on through the kernels that walk whole frontiers
+            materialise_pending = have_seg;
+            if (have_seg && !fuse_ok) // queries that failed the proof go on through the kernels that walk whole frontiers
                 hipLaunchKernelGGL(route_materialise_kernel, dim3(nq), dim3(256), seg_stride(pl.probes) * 4, s, v, pl.seg[cur], pl.probes,
                                    pl.rflag, pl.small_flag, pl.frontier[cur], pl.fstride, pl.fcount[cur]);
         }
@@ -1393,13 +1397,18 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                                  : std::min<uint32_t>((bound + 63) / 64, (shared || (flags & CUDDLE_SEARCH_ROUTE_EXACT_ONLY)) ? 64 : small_gx);
         // after a filter path the exact kernels serve only the queries the filter left (normally none): one block per
         // query would compute their distances, so the selection kernel does it itself and the launch is saved
-        const bool fuse_dist = !keep_all && (use_gemm || grouped_filter) && bound <= 512 * 32 &&
-                               route_select_reg_lds_bytes(scap, v.dim) <= 150 * 1024;
+        const bool fuse_dist = !keep_all && (use_gemm || grouped_filter) && fuse_ok;
         FusedDist fd_args;
         if (fuse_dist) {
             fd_args.queries = dq;
             fd_args.qnorm = pl.qnorm;
             fd_args.fdist = pl.fdist;
+            if (materialise_pending) { // ... and writes out the frontier of a query that only has its segment table
+                fd_args.seg = pl.seg[cur];
+                fd_args.small = pl.small_flag;
+                fd_args.frontier = pl.frontier[cur];
+                fd_args.pstride = pl.probes;
+            }
         }
         if (!keep_all && !fuse_dist)
             hipLaunchKernelGGL(route_dist_kernel, dim3(dist_gx, nq), dim3(256), v.dim * sizeof(float), s, v, dq,

@@ -436,10 +436,16 @@ route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, u
 
 // What route_select_reg_kernel needs to evaluate a query's exact distances itself before it selects (the two kernels
 // that serve queries the matrix-core filter could not decide, as one launch): null queries = distances are in fdist.
+// seg != null: such a query may so far only have its segment table (small[q] == 0): its frontier is written out first
+// (route_materialise_kernel's work), into `frontier`.
 struct FusedDist {
     const float *queries = nullptr;
     const float *qnorm = nullptr;
     float *fdist = nullptr;
+    const uint32_t *seg = nullptr;
+    const uint32_t *small = nullptr;
+    uint32_t *frontier = nullptr;
+    uint32_t pstride = 0;
 };
 
 inline size_t route_select_reg_lds_bytes(uint32_t scap, uint32_t fused_dim = 0) { // route_select_reg_kernel: four radix histograms (+ the query)
@@ -537,6 +543,16 @@ route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride,
     if (only_flag && !only_flag[q]) return;
     const uint32_t n = shared_fr ? shared_n : fcount[q];
     const uint32_t tid = threadIdx.x;
+    if (fused.seg && !fused.small[q]) { // (the selection's key and counter arrays serve as the table's LDS until then)
+        uint32_t *st = reinterpret_cast<uint32_t *>(smem);
+        const uint32_t *sg = fused.seg + (uint64_t)q * seg_stride(fused.pstride);
+        for (uint32_t i = tid; i < seg_stride(fused.pstride); i += blockDim.x) st[i] = sg[i];
+        __syncthreads();
+        const uint32_t nf = min(n, fstride);
+        for (uint32_t o = tid; o < nf; o += blockDim.x) fused.frontier[(uint64_t)q * fstride + o] = frontier_node(ix, st, fused.pstride, o);
+        __threadfence_block();
+        __syncthreads();
+    }
     if (fused.queries && (stats_variant || n > probes)) {
         // the query's exact distances first (route_dist_kernel's work for one block per query), then the selection reads
         // them back: written and read by this block, a barrier apart
