@@ -627,8 +627,12 @@ def run_config(name, args, rank, world, local_rank, device, backend, steps, warm
             del rot
             roofline.update(ceiling_GBps=code_bytes / (read_ms * 1e-3) / 1e9, ceiling_launch_ms=read_ms,
                             scan_launch_ms_same_run=scan_ms_same, frac_of_ceiling=read_ms / scan_ms_same,
+                            per_query_scan_GBps=code_bytes / (scan_ms_same * 1e-3) / 1e9,
+                            per_query_scan_frac=code_bytes / (scan_ms_same * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                             ceiling_queries_per_launch=nqc,
-                            ceiling_note="ceiling = the per-query scan's own reads with no arithmetic, histogram or selection behind them "
+                            ceiling_note="per_query_scan_* = scan_select_hamming_kernel (one block per query, every query reading its own candidates' codes: the kernel the "
+                                         "algorithmic-bytes figure is defined on) timed here on the same batches, whichever scan the timed loop uses; "
+                                         "ceiling = the per-query scan's own reads with no arithmetic, histogram or selection behind them "
                                          "(scan_read_ceiling_kernel: same grid, block, LDS size, tables and loads); both kernels "
                                          f"timed with HIP events over 5 rounds of the same {N_BATCHES} rotating batches")
         except _ffi.CuddleError as e:
@@ -730,7 +734,7 @@ def compact_config(big, wall_s):
             "roofline": {key: r[key] for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
                                                  "algorithmic_bytes_per_launch", "avg_launch_ms", "rerank_GBps",
                                                  "code_array_bytes", "code_array_fits_infinity_cache", "ceiling_GBps",
-                                                 "frac_of_ceiling", "scan_mode") if key in r},
+                                                 "frac_of_ceiling", "scan_mode", "per_query_scan_GBps", "per_query_scan_frac") if key in r},
             "cpu_baseline": cpu, "wall_s": wall_s}
 
 
