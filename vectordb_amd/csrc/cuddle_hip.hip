@@ -986,7 +986,7 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
         lsum += std::min<uint64_t>(sel, ix->level_leaves[l]); // a level contributes at most its own leaves
         fb = sel * std::max<uint32_t>(ix->max_children, 1);
     }
-    pl.fstride = (uint32_t)align_up(fmax, 4);
+    pl.fstride = (uint32_t)align_up(fmax, 32); // rows of the distance matrix start on 128-byte lines: the contraction's 128-byte stores stay whole
     pl.lstride = (uint32_t)align_up(std::max<uint64_t>(std::min<uint64_t>(lsum, ix->n_leaves), std::max<uint32_t>(lstride_min, 1)), 4);
     uint64_t cbound = std::min<uint64_t>((uint64_t)pl.lstride * ix->max_leaf, v.n_vectors);
     if (cbound >= kMaxCandidates || pl.lstride >= (1u << 20))
