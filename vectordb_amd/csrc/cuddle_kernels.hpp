@@ -441,8 +441,8 @@ __device__ __forceinline__ void chunked_threshold_select(WordPtr words, uint32_t
 // reads it 64 consecutive words at a time. Pass 1 counts; pass 2 ranks the keys of a step by two wave scans, and only
 // in steps that hold a selected key at all (the selection is a small part of the candidates). Keys are compared field
 // by field (any T). wtmp needs 2 * (blockDim.x / 64) u32. All threads call; contains two barriers.
-template <class DistT, class EmitFn>
-__device__ __forceinline__ void wave_threshold_select(const uint32_t *words, uint32_t C, uint32_t T, uint32_t budget,
+template <class DistT, class WordPtr, class EmitFn>
+__device__ __forceinline__ void wave_threshold_select(WordPtr words, uint32_t C, uint32_t T, uint32_t budget,
                                                       EmitFn emit, uint32_t *wtmp) {
     constexpr uint32_t EPW = 4 / sizeof(DistT), BITS = 8 * sizeof(DistT), MASK = (1u << BITS) - 1;
     const uint32_t nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1313,6 +1313,7 @@ scan_select_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *
     auto to_stage = [&](uint32_t i, uint32_t rank) { if (rank < nsel) stg[rank] = i; };
     auto to_row = [&](uint32_t i, uint32_t rank) { if (rank < nsel) sp[rank] = i; };
     if constexpr (in_lds) {
+        // (the wave-by-wave walk below, tried on LDS: 0.377 -> 0.399 ms per 10 000 queries at 750 of 11 460 selected)
         if (stage_lds) chunked_threshold_select<DistT>(dist_words, C, T, budget, to_stage, s.wtmp);
         else chunked_threshold_select<DistT>(dist_words, C, T, budget, to_row, s.wtmp);
     } else { // keys in the spill row: read wave by wave, coalesced
