@@ -607,7 +607,8 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
                 level_pos[v2] = (uint32_t)i;
                 if (d->child_offsets[v2 + 1] == d->child_offsets[v2]) ix->level_leaves[l]++;
             }
-            if (l + 1 < n_levels) ix->max_parent_width = std::max(ix->max_parent_width, (uint32_t)level_nodes[l].size());
+            if (l + 1 < n_levels) // (in pair counters: a narrow level has several per parent)
+                ix->max_parent_width = std::max(ix->max_parent_width, (uint32_t)level_nodes[l].size() << pair_shift_of((uint32_t)level_nodes[l].size()));
             ST_TRY(upload(ix, level_nodes[l].data(), level_nodes[l].size(), &ix->lvl[l].nodes));
         }
         uint32_t *lp;
@@ -1271,7 +1272,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
         uint32_t grouped_kc = 0;
         if (grouped) {
             // pairs recorded by the level above -> parent order -> one block per (parent, 8 queries)
-            const uint32_t wprev = ix->level_width[l - 1], total = nq * pl.probes;
+            const uint32_t psh = pair_shift_of(ix->level_width[l - 1]); // counters per parent of the level above (PairOut::shift)
+            const uint32_t wprev = ix->level_width[l - 1] << psh, total = nq * pl.probes;
             grouped_filter = !stats && g.n && bound <= 512 * 32 && !no_filter && finish_fits(bound);
             const uint32_t nb = (wprev + kPairScanChunk - 1) / kPairScanChunk; // pl.grp_fill: 2 * nb block sums / offsets
             const bool self_carry = nb <= 16; // few chunks: pair_scan_kernel sums the chunks before its own itself
@@ -1280,7 +1282,8 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 hipLaunchKernelGGL(pair_block_scan_kernel, dim3(1), dim3(1024), 0, s, pl.grp_fill, nb, wprev, pl.grp_poff, pl.grp_ioff);
             }
             hipLaunchKernelGGL(pair_scan_kernel, dim3(nb), dim3(256), 0, s, pl.grp_cnt, wprev, self_carry ? nullptr : pl.grp_fill, nb, pl.grp_poff, pl.grp_ioff,
-                               reinterpret_cast<uint4 *>(pl.grp_item), grouped_filter ? ix->lvl[l - 1].child_rows : nullptr);
+                               reinterpret_cast<uint4 *>(pl.grp_item), grouped_filter ? ix->lvl[l - 1].child_rows : nullptr,
+                               (uint32_t *)nullptr, (const uint32_t *)nullptr, psh);
             hipLaunchKernelGGL(pair_fill_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pl.pair_info, pl.pair_parent, pl.pair_slot,
                                total, pl.grp_poff, pl.pair_sorted);
             const uint32_t items = (total + kGroupPairs - 1) / kGroupPairs + std::min(wprev, total);
@@ -1346,13 +1349,14 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 group_next = true;
                 po.info = pl.pair_info; po.parent = pl.pair_parent; po.slot = pl.pair_slot; po.cnt = pl.grp_cnt; po.small = pl.small_flag;
                 po.pstride = pl.probes;
+                po.shift = pair_shift_of(ix->level_width[l]);
                 po.min_n = stats ? 0u : std::max<uint32_t>(pl.probes, 100);
                 // the next level will go through the contraction (the condition of grouped_filter there): its kernels
                 // need a frontier position's node for a few hundred positions per query, not the frontier itself
                 seg_next = !stats && ix->lvl[l + 1].n && bound_next <= 512 * 32 && !no_filter && finish_fits(bound_next);
                 if (seg_next) po.seg = pl.seg[cur ^ 1];
                 if (use_gemm) zero_cnt = pl.grp_cnt;
-                else HIP_TRY(hipMemsetAsync(pl.grp_cnt, 0, ((size_t)ix->level_width[l] + 1) * 4, s));
+                else HIP_TRY(hipMemsetAsync(pl.grp_cnt, 0, (((size_t)ix->level_width[l] << po.shift) + 1) * 4, s));
             }
         }
         if (grouped_finish) {
@@ -1378,7 +1382,7 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                                    pl.kc_cap, pl.rc_max);
             hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                g.nodes, pl.rc_pos, pl.kc_cap, kc, pl.rc_dist, pl.qnorm, 0u, (const uint32_t *)nullptr,
-                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, zero_cnt, ix->level_width[l] + 1);
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, zero_cnt, (ix->level_width[l] << po.shift) + 1);
             hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(kc), pl.probes), s,
                                v, g.nodes, n, pl.rc_pos, pl.rc_dist, pl.kc_cap, kc, pl.rc_max, pl.qsq, g.max_sqn, pl.probes,
                                pl.frontier[cur ^ 1], pl.fstride, pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,

@@ -149,6 +149,11 @@ struct PairOut {
     uint32_t *small = nullptr;
     uint32_t pstride = 0;
     uint32_t min_n = 0;
+    // A level of few parents takes a pair from nearly every query for every parent: thousands of returning atomic adds
+    // on each of a hundred counters, one after the other. Such a level counts into 2^shift counters per parent instead
+    // (counter = parent << shift | query & (2^shift - 1)); the pair machinery then sees 2^shift parents for every
+    // real one, adjacent, so that a parent's pairs still lie together (pair_shift_of, pair_scan_kernel).
+    uint32_t shift = 0;
     // seg != null: a grouped query's next frontier is not written out node by node; the query gets its
     // segment table instead (seg + q * seg_stride(pstride)): start[0..pstride] = position of each chosen
     // node's first child in the frontier (entries past the selection = the frontier's size), then
@@ -280,7 +285,7 @@ __device__ __forceinline__ void route_expand_fn(const IndexDev &ix, NodeFn node_
         for (uint32_t i = tid; i < po.pstride; i += blockDim.x) {
             uint32_t info = 0xFFFFFFFFu, par = 0, slot = 0;
             if (grouped && i < nsel && cnt_child[i + 1] > cnt_child[i]) {
-                par = ix.level_pos[sel_node[i]];
+                par = (ix.level_pos[sel_node[i]] << po.shift) | (q & ((1u << po.shift) - 1));
                 info = (q << kPairOffBits) | cnt_child[i];
                 slot = atomicAdd(&po.cnt[par], 1u);
             }
@@ -650,6 +655,12 @@ route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride,
 //   pair_block_scan_kernel  one block of 1024: bsum -> exclusive offsets in place; totals to poff[n], ioff[n]
 //   pair_scan_kernel        grid nb, block 256: offsets of each parent, and its items
 constexpr uint32_t kPairScanChunk = 1024; // parents per block: 4 per thread
+// Counters per parent (as a shift) for a level of `width` parents: up to 16, while the level stays under 2048 counters.
+__host__ __device__ inline uint32_t pair_shift_of(uint32_t width) {
+    uint32_t sh = 0;
+    while (sh < 4 && ((uint64_t)width << (sh + 1)) <= 2048) ++sh;
+    return sh;
+}
 
 __device__ __forceinline__ uint32_t pair_items_of(uint32_t c) { return (c + kGroupPairs - 1) / kGroupPairs; }
 
@@ -729,7 +740,8 @@ pair_block_scan_kernel(uint32_t *bsum, uint32_t nb, uint32_t n, uint32_t *poff, 
 
 __global__ void __launch_bounds__(256)
 pair_scan_kernel(const uint32_t *cnt, uint32_t n, const uint32_t *bsum, uint32_t nb, uint32_t *poff, uint32_t *ioff,
-                 uint4 *items, const uint2 *child_rows, uint32_t *work_bins = nullptr, const uint32_t *vec_off = nullptr) {
+                 uint4 *items, const uint2 *child_rows, uint32_t *work_bins = nullptr, const uint32_t *vec_off = nullptr,
+                 uint32_t shift = 0) { // shift: entry i counts for parent i >> shift (PairOut::shift)
     __shared__ uint32_t lds8[8];
     static_assert(kWorkBins == 256, "one work class per thread of the block");
     __shared__ uint32_t wb[kWorkBins]; // this block's items per work class (one global add per class and block)
@@ -789,13 +801,13 @@ pair_scan_kernel(const uint32_t *cnt, uint32_t n, const uint32_t *bsum, uint32_t
         poff[i] = rp;
         ioff[i] = ri;
         if (ni) {
-            const uint2 cr = child_rows ? child_rows[i] : make_uint2(0u, 0u);
+            const uint2 cr = child_rows ? child_rows[i >> shift] : make_uint2(0u, 0u);
             // work_bins != null (parents are leaves, vec_off their vector ranges): the items are also counted by work,
             // for item_scatter_kernel to put them in heaviest-first order
             const uint32_t nv = work_bins ? vec_off[i + 1] - vec_off[i] : 0u;
             for (uint32_t t = 0; t < ni; ++t) {
                 const uint32_t first = rp + t * kGroupPairs, np = min((uint32_t)kGroupPairs, c - t * kGroupPairs);
-                items[ri + t] = child_rows ? make_uint4(first, np, cr.x, cr.y) : make_uint4(i, first, np, 0u);
+                items[ri + t] = child_rows ? make_uint4(first, np, cr.x, cr.y) : make_uint4(i >> shift, first, np, 0u);
                 if (work_bins) atomicAdd(&wb[item_work_bin(np, nv)], 1u);
             }
         }
