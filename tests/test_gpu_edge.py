@@ -133,6 +133,20 @@ def test_tie_heavy_selection(gpu):
     _compare_full(fi, dev, q, 3, 10, 7)
 
 
+@pytest.mark.parametrize("code_kind", ["binary", "rabitq"])
+def test_top_k_of_selections_between_1024_and_2048(gpu, code_kind):
+    """k = 10 of 1500 and of 2040 reranked candidates: the one-wave top-k with 32 keys per lane (duplicates in the data,
+    so that equal distances are ordered by the phase-1 order)."""
+    x = clustered(30000, 24, 60, 12, sigma=0.3)
+    x[1000:1100] = x[2000:2100]
+    fi = build_index(x, 20, 60, "l2", 6, seed=6, code_kind=code_kind)
+    dev = DeviceIndex(fi, gpu)
+    q = queries_like(x, 24, 8)
+    q[0] = x[1000]
+    _compare_full(fi, dev, q, 10, 60, 150)
+    _compare_full(fi, dev, q, 10, 60, 204)
+
+
 def test_rerank_cap_and_spill_path(gpu):
     """probes large enough that one query scans > 24576 candidates (the LDS capacity of the scan
     kernel: distances go to the global spill buffer) and k*rerank_factor hits the 10 000 cap."""
