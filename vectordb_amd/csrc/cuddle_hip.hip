@@ -772,6 +772,7 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     (void)hipFuncSetAttribute((const void *)rerank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_dist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)route_dist_roots_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // the leaf tables of the sharded selection steps: 16 bytes per leaf slot
     (void)hipFuncSetAttribute((const void *)shard_ties_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)shard_ties_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1414,7 +1415,14 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
                 fd_args.pstride = pl.probes;
             }
         }
-        if (!keep_all && !fuse_dist)
+        // fewer probes than roots: every query measures the same few centroids, which then come from LDS
+        const bool roots_path = !keep_all && !fuse_dist && sfr && !stats && !only && sn >= 4 && sn <= 100 &&
+                                route_dist_roots_lds_bytes(v.dim, sn) <= 80 * 1024;
+        if (roots_path)
+            hipLaunchKernelGGL(route_dist_roots_kernel, dim3(std::min<uint32_t>((nq + kRootsWaves - 1) / kRootsWaves, 512)),
+                               dim3(64 * kRootsWaves), route_dist_roots_lds_bytes(v.dim, sn), s, v, dq, nq, sfr, sn,
+                               route_dist_roots_stride(v.dim), pl.fdist, pl.fstride);
+        else if (!keep_all && !fuse_dist)
             hipLaunchKernelGGL(route_dist_kernel, dim3(dist_gx, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
                                pl.frontier[cur], pl.fstride, pl.fcount[cur], sfr, sn, pl.fdist, pl.probes, stats, only, pl.qnorm);
         const uint32_t *sel_only = (grouped && !grouped_filter) ? nullptr : only; // after the exact grouped path every query still selects here

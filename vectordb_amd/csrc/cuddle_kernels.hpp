@@ -641,6 +641,39 @@ __device__ __forceinline__ float l2_batch4_serial(const float *q, const float *t
     return r;
 }
 
+// l2_batch4_serial by a 4-lane group: lane `sub` keeps lane `sub` of the accumulator (elements i = sub mod 4, in
+// order), the quad adds them as vaddvq does, (a0 + a1) + (a2 + a3), and the tail is added in order. Every lane returns
+// the result. All four lanes of the group call.
+__device__ __forceinline__ float l2_batch4_group4(const float *q, const float *t, uint32_t n, uint32_t sub) {
+    float a = 0.f;
+    const uint32_t n4 = n & ~3u;
+    uint32_t i = sub;
+    for (; i + 28 < n4; i += 32) { // eight steps of the chain with their sixteen loads in flight together
+        float qv[8], tv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            qv[k] = q[i + 4 * k];
+            tv[k] = t[i + 4 * k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float d = qv[k] - tv[k];
+            a = __builtin_fmaf(d, d, a);
+        }
+    }
+    for (; i < n4; i += 4) {
+        const float d = q[i] - t[i];
+        a = __builtin_fmaf(d, d, a);
+    }
+    a += quad_xor1(a); // lanes 0, 1: a0 + a1; lanes 2, 3: a2 + a3
+    float r = a + quad_xor2(a); // (a0 + a1) + (a2 + a3) in every lane (the additions commute)
+    for (uint32_t i = n4; i < n; ++i) {
+        const float d = q[i] - t[i];
+        r += d * d;
+    }
+    return r;
+}
+
 // distance() (src/distance/mod.rs:23-34) by a 4-lane group. a = query side, b = stored side.
 __device__ __forceinline__ float distance_group4(const float *a, const float *b, uint32_t n, uint32_t metric,
                                                  uint32_t sub, bool vec) {

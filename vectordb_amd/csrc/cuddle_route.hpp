@@ -439,6 +439,55 @@ route_dist_kernel(IndexDev ix, const float *queries, const uint32_t *frontier, u
                      stats_variant, ix.metric == kMetricCosine ? qnorm[q] : 0.f, blockIdx.x, gridDim.x);
 }
 
+// route_dist_kernel for a level whose frontier is shared by every query and takes the batch arithmetic (4 <= n <= 100
+// nodes: the roots of a tree searched with fewer probes than it has roots). With a block per query every block would
+// read the same n centroids from L2 (50 KB for 100 x 128, past what a CU's L1 keeps: 4096 queries were 60 us of L2
+// reads); here a block of 16 waves stages them in LDS once and each wave serves one query at a time, a 4-lane group per
+// node. Rows are `cstride` floats apart, cstride = 4 (mod 64) and >= dim: the 16 groups of a wave then read 64
+// different banks. grid: any (waves stride over the queries), block 1024, LDS route_dist_roots_lds_bytes(dim, n).
+constexpr uint32_t kRootsWaves = 16;
+inline uint32_t route_dist_roots_stride(uint32_t dim) { return dim + ((68 - (dim & 63)) & 63); }
+inline size_t route_dist_roots_lds_bytes(uint32_t dim, uint32_t n) {
+    return ((size_t)n * route_dist_roots_stride(dim) + (size_t)kRootsWaves * ((dim + 3) & ~3u)) * sizeof(float);
+}
+__global__ void __launch_bounds__(1024)
+route_dist_roots_kernel(IndexDev ix, const float *queries, uint32_t nq, const uint32_t *shared_fr, uint32_t n, uint32_t cstride,
+                        float *fdist, uint32_t fstride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t D = ix.dim, D4 = (D + 3) & ~3u;
+    float *cs = reinterpret_cast<float *>(smem);
+    float *qw = cs + (size_t)n * cstride + (threadIdx.x >> 6) * D4; // this wave's query
+#pragma unroll 4
+    for (uint32_t row = threadIdx.x >> 6; row < n; row += kRootsWaves) { // a wave per row: coalesced
+        const float *c = ix.centroids + (uint64_t)shared_fr[row] * D;
+        for (uint32_t i = threadIdx.x & 63; i < D; i += 64) cs[row * cstride + i] = c[i];
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, sub = lane & 3, g = lane >> 2, n4 = n & ~3u;
+    const bool vec = (D & 3) == 0;
+    for (uint32_t q = blockIdx.x * kRootsWaves + (threadIdx.x >> 6); q < nq; q += gridDim.x * kRootsWaves) { // wave-uniform
+        __builtin_amdgcn_wave_barrier(); // the last query's reads are behind us (LDS serves a wave in order)
+        for (uint32_t i = lane; i < D; i += 64) qw[i] = queries[(uint64_t)q * D + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j0 = 0; j0 < n; j0 += 16) {
+            const uint32_t j = j0 + g;
+            const bool act = j < n;
+            const float *c = cs + (act ? j : 0) * cstride;
+            float d;
+            if (j0 + 16 <= n4) // (wave-uniform) sixteen nodes of the batch-of-four arithmetic
+                d = l2_batch4_group4(qw, c, D, sub);
+            else if (j0 >= n4) // the 1..3 nodes past the last whole batch: l2_squared
+                d = neon16_group4<true>(qw, c, D, sub, vec);
+            else {
+                const float db = l2_batch4_group4(qw, c, D, sub), ds = neon16_group4<true>(qw, c, D, sub, vec);
+                d = j < n4 ? db : ds;
+            }
+            if (act && sub == 0) fdist[(uint64_t)q * fstride + j] = d;
+        }
+    }
+}
+
 // What route_select_reg_kernel needs to evaluate a query's exact distances itself before it selects (the two kernels
 // that serve queries the matrix-core filter could not decide, as one launch): null queries = distances are in fdist.
 // seg != null: such a query may so far only have its segment table (small[q] == 0): its frontier is written out first
@@ -655,10 +704,10 @@ route_select_reg_kernel(IndexDev ix, const uint32_t *frontier, uint32_t fstride,
 //   pair_block_scan_kernel  one block of 1024: bsum -> exclusive offsets in place; totals to poff[n], ioff[n]
 //   pair_scan_kernel        grid nb, block 256: offsets of each parent, and its items
 constexpr uint32_t kPairScanChunk = 1024; // parents per block: 4 per thread
-// Counters per parent (as a shift) for a level of `width` parents: up to 16, while the level stays under 2048 counters.
+// Counters per parent (as a shift) for a level of `width` parents: up to 64, while the level stays under 8192 counters.
 __host__ __device__ inline uint32_t pair_shift_of(uint32_t width) {
     uint32_t sh = 0;
-    while (sh < 4 && ((uint64_t)width << (sh + 1)) <= 2048) ++sh;
+    while (sh < 6 && ((uint64_t)width << (sh + 1)) <= 8192) ++sh;
     return sh;
 }
 
