@@ -66,3 +66,26 @@ def test_ties_flood_the_prefilter(gpu):
     q = rng.standard_normal((40, d)).astype(np.float32)
     assert _lists(dev, q, 100) == _lists(dev, q, 100, _ffi.SEARCH_ROUTE_EXACT_ONLY)
     assert _lists(dev, q, 300) == _lists(dev, q, 300, _ffi.SEARCH_ROUTE_EXACT_ONLY)
+
+
+@pytest.mark.parametrize("dim,roots,probes", [(5, 4, 3), (24, 7, 4), (130, 33, 20), (128, 99, 85), (128, 100, 50),
+                                               (64, 18, 17)])
+def test_fewer_probes_than_roots(gpu, dim, roots, probes):
+    """4..100 roots and fewer probes than roots: every query picks among the same few root centroids, in the
+    batch-of-four arithmetic for the first 4 * floor(n / 4) of them and l2_squared's for the rest
+    (hierarchical.rs:355-391), whatever the metric. The roots come from LDS on this path; lists and results must
+    equal the oracle's for every query."""
+    from oracle import oracle as orc
+
+    device = torch.device("cuda", gpu)
+    dti, queries = build_tree_index_on_device(dim, roots, 2, 3, device, seed=roots, n_queries=50, style="gauss",
+                                              metric=_ffi.METRIC_COSINE if roots == 33 else _ffi.METRIC_L2)
+    dev = dti.create(gpu)
+    q = queries.cpu().numpy()
+    got = _lists(dev, q, probes)
+    ids, dist, cnt = dev.search_batch(q, 5, probes, 3)
+    oi = orc.OracleIndex(dti.to_flat())
+    for i in range(q.shape[0]):
+        t = oi.search(q[i], 5, probes, 3, trace=True)
+        assert got[i] == [int(v) for v in t["leaves"]], i
+        assert np.array_equal(ids[i, :cnt[i]], t["ids"][:t["count"]]), i
