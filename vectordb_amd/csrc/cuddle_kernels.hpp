@@ -55,18 +55,19 @@ struct IndexDev {
 
 // Debug builds (-DCUDDLE_STAMP_KERNEL=<id>) record the 100 MHz clock at up to 8 points of every
 // block of ONE kernel (1 Hamming scan, 2 grouped routing distances, 3 register selection,
-// 4 routing finish, 5 register prefilter, 6 RaBitQ scan); cuddle_debug_stamps() reads them back.
+// 4 routing finish, 5 register prefilter, 6 RaBitQ scan, 10 leaf-by-leaf scan, 11 rerank); cuddle_debug_stamps() reads them back.
 #ifdef CUDDLE_STAMP_KERNEL
 constexpr uint32_t kStampBlocks = 16384;
 __device__ uint64_t g_dbg_stamps[kStampBlocks * 8];
-#define CUDDLE_STAMP(kernel_id, n)                                                                   \
+#define CUDDLE_STAMP_AT(kernel_id, n, block)                                                         \
     do {                                                                                             \
-        if ((kernel_id) == CUDDLE_STAMP_KERNEL && threadIdx.x == 0 && blockIdx.x < kStampBlocks)     \
-            g_dbg_stamps[blockIdx.x * 8 + (n)] = wall_clock64();                                     \
+        if ((kernel_id) == CUDDLE_STAMP_KERNEL && threadIdx.x == 0 && (block) < kStampBlocks)        \
+            g_dbg_stamps[(block) * 8 + (n)] = wall_clock64();                                        \
     } while (0)
 #else
-#define CUDDLE_STAMP(kernel_id, n) do { } while (0)
+#define CUDDLE_STAMP_AT(kernel_id, n, block) do { } while (0)
 #endif
+#define CUDDLE_STAMP(kernel_id, n) CUDDLE_STAMP_AT(kernel_id, n, blockIdx.x)
 
 // Order-preserving map f32 -> u32 for "a < b" comparisons as the reference's partial_cmp sees
 // them: -0.0 == +0.0, NaN after everything.
@@ -595,6 +596,49 @@ __device__ __forceinline__ float neon16_group4(const float *a, const float *b, u
     return neon_tail<L2>(group4_reduce(acc), a, b, nblk << 4, n);
 }
 
+// neon16_group4 / neon16_group4_dot2 for a row b that comes from far away (a random row of the fp32 vectors in HBM):
+// U of the row's 16-byte pieces per lane are requested before the first is used, so a 3840-byte row takes 4 trips to
+// memory instead of 15 and its pieces reach the DRAM page together. Same chains, same values.
+template <bool L2, bool BB, int U>
+__device__ __forceinline__ void neon16_group4_far(const float *a, const float *b, uint32_t n, uint32_t sub, bool vec, float &ab,
+                                                  float &bb) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acb = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t nblk = n >> 4;
+    const float *pa = a + 4 * sub, *pb = b + 4 * sub;
+    auto step = [&](const float4 x, const float4 y) {
+        if (L2) {
+            const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+            acc.x = __builtin_fmaf(d0, d0, acc.x);
+            acc.y = __builtin_fmaf(d1, d1, acc.y);
+            acc.z = __builtin_fmaf(d2, d2, acc.z);
+            acc.w = __builtin_fmaf(d3, d3, acc.w);
+        } else {
+            acc.x = __builtin_fmaf(x.x, y.x, acc.x);
+            acc.y = __builtin_fmaf(x.y, y.y, acc.y);
+            acc.z = __builtin_fmaf(x.z, y.z, acc.z);
+            acc.w = __builtin_fmaf(x.w, y.w, acc.w);
+        }
+        if (BB) {
+            acb.x = __builtin_fmaf(y.x, y.x, acb.x);
+            acb.y = __builtin_fmaf(y.y, y.y, acb.y);
+            acb.z = __builtin_fmaf(y.z, y.z, acb.z);
+            acb.w = __builtin_fmaf(y.w, y.w, acb.w);
+        }
+    };
+    uint32_t t = 0;
+    for (; t + U <= nblk; t += U) {
+        float4 y[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) y[k] = ld4(pb + 16 * (t + k), vec);
+#pragma unroll
+        for (int k = 0; k < U; ++k) step(ld4(pa + 16 * (t + k), vec), y[k]);
+    }
+#pragma unroll 4
+    for (; t < nblk; ++t) step(ld4(pa + 16 * t, vec), ld4(pb + 16 * t, vec));
+    ab = neon_tail<L2>(group4_reduce(acc), a, b, nblk << 4, n);
+    if (BB) bb = neon_tail<false>(group4_reduce(acb), b, b, nblk << 4, n);
+}
+
 // The same routines computed by one lane (16 running partial sums).
 template <bool L2>
 __device__ __forceinline__ float neon16_serial(const float *a, const float *b, uint32_t n) {
@@ -788,6 +832,23 @@ __global__ void query_norm_kernel(const float *queries, uint32_t nq, uint32_t di
     const float *q = queries + (uint64_t)(act ? g : 0) * dim;
     const float s = neon16_group4<false>(q, q, dim, sub, (dim & 3) == 0);
     if (act && sub == 0) qnorm[g] = sqrtf(s);
+}
+
+// distance_group4_qn for a far row (see neon16_group4_far).
+template <int U>
+__device__ __forceinline__ float distance_group4_qn_far(const float *a, const float *b, uint32_t n, uint32_t metric, uint32_t sub,
+                                                        bool vec, float na) {
+    float ab, bb = 0.f;
+    if (metric == kMetricL2) {
+        neon16_group4_far<true, false, U>(a, b, n, sub, vec, ab, bb);
+        return ab;
+    }
+    if (metric == kMetricDot) {
+        neon16_group4_far<false, false, U>(a, b, n, sub, vec, ab, bb);
+        return -ab;
+    }
+    neon16_group4_far<false, true, U>(a, b, n, sub, vec, ab, bb);
+    return 1.0f - (ab / (na * sqrtf(bb)));
 }
 
 __device__ __forceinline__ float distance_serial(const float *a, const float *b, uint32_t n, uint32_t metric) {
@@ -1724,7 +1785,11 @@ scan_all_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *lea
 // distance(query, full_vectors.get(idx), metric) for every selected candidate. grid =
 // (ceil(sel_stride/64), nq), block 256: the query is staged in LDS once per block, each 4-lane
 // group streams one candidate row with 128-bit loads (64 contiguous bytes per group and step).
-__global__ void __launch_bounds__(256)
+#ifndef CUDDLE_RERANK_U
+#define CUDDLE_RERANK_U 8
+#define CUDDLE_RERANK_W 8
+#endif
+__global__ void __launch_bounds__(256, CUDDLE_RERANK_W)
 rerank_kernel(IndexDev ix, const float *queries, const uint32_t *sel_pos, uint32_t sel_stride,
               const uint32_t *sel_count, float *sel_dist, const float *qnorm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1732,19 +1797,22 @@ rerank_kernel(IndexDev ix, const float *queries, const uint32_t *sel_pos, uint32
     const uint32_t q = blockIdx.y;
     const uint32_t n = sel_count[q];
     if (blockIdx.x * 64 >= n) return;
+    CUDDLE_STAMP_AT(11, 0, blockIdx.y * gridDim.x + blockIdx.x);
     const uint32_t D = ix.dim;
     const float *qg = queries + (uint64_t)q * D;
     for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) qs[i] = qg[i];
     __syncthreads();
+    CUDDLE_STAMP_AT(11, 1, blockIdx.y * gridDim.x + blockIdx.x);
     const uint32_t j = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
     // a group past the selection does nothing: its four lanes leave together, so the quad exchanges of the groups
     // that stay are among active lanes only (and it reads no row)
     if (j >= n) return;
     const uint32_t pos = sel_pos[(uint64_t)q * sel_stride + j];
     const bool vec = (D & 3) == 0;
-    float d = distance_group4_qn(qs, ix.vectors + (uint64_t)pos * D, D, ix.metric, sub, vec,
-                                 ix.metric == kMetricCosine ? qnorm[q] : 0.f);
+    float d = distance_group4_qn_far<CUDDLE_RERANK_U>(qs, ix.vectors + (uint64_t)pos * D, D, ix.metric, sub, vec,
+                                         ix.metric == kMetricCosine ? qnorm[q] : 0.f);
     if (sub == 0) sel_dist[(uint64_t)q * sel_stride + j] = d;
+    CUDDLE_STAMP_AT(11, 2, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // finalize_results: ascending by (distance, phase-1 order). For the Hamming path phase-1 order is
