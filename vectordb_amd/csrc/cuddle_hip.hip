@@ -1015,6 +1015,26 @@ static cuddle_status make_plan(cuddle_index *ix, uint32_t nq, uint32_t k, uint32
     if (v.code_kind == CUDDLE_CODE_BINARY) {
         const uint32_t esz = v.dim < 255 ? 1 : 2; // one byte per distance when dim < 255
         pl.dist_cap = std::min<uint32_t>(pl.cstride, kLdsDistCap * 2 / esz);
+        // cstride is the worst case (every reached leaf as large as the largest); a distance array of that size can
+        // halve the blocks a CU holds (SIFT1M shape: 57 KB per block, 2 blocks of 8 waves where the registers allow
+        // 4; 0.379 -> 0.274 ms per 10 000 queries with 4). So: the most blocks per CU whose share of the LDS still
+        // holds half as many candidates again as a query reaches on average; a query beyond that keeps its distances
+        // in its row of the spill buffer, as one beyond the old size did.
+        const size_t fixed = scan_lds_bytes(v.dim, v.words, pl.lstride, pl.tcap, 0, v.words == 2);
+        // (on average: a leaf of average size for every probe of the last level; lstride also counts what every
+        // level above could add)
+        const uint64_t typical = (uint64_t)std::min(pl.lstride, pl.probes) * v.n_vectors / std::max<uint32_t>(ix->n_leaves, 1) * 3 / 2;
+        for (uint32_t blocks = 2048 / pl.scan_threads; blocks >= 1; --blocks) {
+            const size_t share = 160 * 1024 / blocks - 512;
+            if (share <= fixed) continue;
+            const uint32_t fit = (uint32_t)((share - fixed) / esz) & ~127u;
+            if (fit >= std::min<uint64_t>(pl.dist_cap, typical) || blocks == 1) {
+                pl.dist_cap = std::min(pl.dist_cap, std::max(fit, 128u));
+                break;
+            }
+        }
+        if (const char *e = getenv("CUDDLE_LDS_DIST_BYTES")) // tuning aid
+            pl.dist_cap = std::max<uint32_t>(128, std::min<uint32_t>(std::min<uint32_t>(pl.cstride, kLdsDistCap * 2 / esz), (uint32_t)atoi(e) / esz));
         pl.scan_lds = scan_lds_bytes(v.dim, v.words, pl.lstride, pl.tcap, (pl.dist_cap * esz + 1) / 2, v.words == 2);
     } else {
         pl.dist_cap = std::min(pl.cstride, kLdsDistCap / 2); // f32 estimates
