@@ -1,11 +1,12 @@
 """Does replaying one search as a captured HIP graph beat launching its kernels one by one?
 
-    python tools/graph_replay_probe.py <config> <rerank_factor> [steps]
+    python tools/graph_replay_probe.py <config> <rerank_factor> [steps] [queries per call]
 
 Builds the configuration's index as bench.py does, warms the handle up (work space allocated, routing
 filters settled), captures one cuddle_search_batch_device call into a graph (relaxed capture mode: the
 call's event query for the routing-filter feedback is left alone), and times `steps` direct calls
-against `steps` replays on the same query batch. Prints one JSON line. Development tool.
+against `steps` replays on the same query batch, back to back and with a synchronisation after every call (the
+latency a caller sees for one small request). Prints one JSON line. Development tool.
 """
 import json
 import os
@@ -48,6 +49,8 @@ def main():
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     idx, queries, keep = build(name, device)
+    if len(sys.argv) > 4:
+        queries = queries[:int(sys.argv[4])].contiguous()
     nq, k, probes = queries.shape[0], cfg["k"], cfg["probes"]
     out = (torch.empty((nq, k), dtype=torch.int64, device=device), torch.empty((nq, k), dtype=torch.float32, device=device),
            torch.empty((nq,), dtype=torch.int32, device=device))
@@ -79,7 +82,18 @@ def main():
             g.replay()
         torch.cuda.synchronize()
         replay = (time.perf_counter() - t0) / steps
-    print(json.dumps({"config": name, "rerank_factor": rf, "steps": steps, "direct_ms": direct * 1e3, "graph_replay_ms": replay * 1e3,
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            idx.search_batch_device(queries, k, probes, rf, 0, *out)
+            torch.cuda.synchronize()
+        direct_sync = (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+            torch.cuda.synchronize()
+        replay_sync = (time.perf_counter() - t0) / steps
+    print(json.dumps({"config": name, "queries_per_call": nq, "rerank_factor": rf, "steps": steps, "direct_ms": direct * 1e3,
+                      "graph_replay_ms": replay * 1e3, "direct_synced_ms": direct_sync * 1e3, "graph_replay_synced_ms": replay_sync * 1e3,
                       "replay_results_identical": same}))
 
 

@@ -45,6 +45,8 @@ def main():
         fi = build_index(base, cfg["branching"], cfg["leaf"], cfg["metric"], 20, seed=1, code_kind=cfg["code_kind"],
                          threshold="mean")
         idx = DeviceIndex(fi, 0)
+    if os.environ.get("CUDDLE_PROBE_NQ"):  # a small request instead of the configuration's batch
+        queries = queries[:int(os.environ["CUDDLE_PROBE_NQ"])].contiguous()
     nq, k = queries.shape[0], cfg["k"]
     ids = torch.empty((nq, k), dtype=torch.int64, device=device)
     dd = torch.empty((nq, k), dtype=torch.float32, device=device)

@@ -764,7 +764,8 @@ extern "C" cuddle_status cuddle_index_create(const cuddle_index_desc *d, int dev
     (void)hipFuncSetAttribute((const void *)route_select_reg_kernel<512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)grouped_kernel_for(v.dim, v.metric), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)route_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)rabitq_query_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)rabitq_query_prep_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)rabitq_query_prep_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_select_rabitq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)scan_all_rabitq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)selection_sort_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1135,8 +1136,11 @@ static cuddle_status launch_quantize(cuddle_index *ix, const Plan &pl, const flo
         }
     } else {
         float *rq = reinterpret_cast<float *>(pl.qcodes), *qn = rq + (size_t)pl.qc * v.dim;
-        hipLaunchKernelGGL(rabitq_query_prep_kernel, dim3((nq + kPrepQ - 1) / kPrepQ), dim3(std::min(1024u, (v.dim + 63) & ~63u)), kPrepQ * v.dim * sizeof(float),
-                           s, dq, v.rot, nq, v.dim, rq, qn);
+        const dim3 pgrid((nq + kPrepQ - 1) / kPrepQ, (v.dim + kPrepRows - 1) / kPrepRows);
+        if (pgrid.x * pgrid.y <= 256) // fewer blocks than CUs: each thread's chain of loads is the whole cost
+            hipLaunchKernelGGL(rabitq_query_prep_kernel<64>, pgrid, dim3(kPrepRows), kPrepQ * v.dim * sizeof(float), s, dq, v.rot, nq, v.dim, rq, qn);
+        else
+            hipLaunchKernelGGL(rabitq_query_prep_kernel<32>, pgrid, dim3(kPrepRows), kPrepQ * v.dim * sizeof(float), s, dq, v.rot, nq, v.dim, rq, qn);
         hipLaunchKernelGGL(rabitq_query_planes_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, rq, qn, nq, v.dim, v.words32, pl.rq_rows,
                            pl.rq_grouped ? pl.rq_i8 : (int8_t *)nullptr);
     }

@@ -18,51 +18,73 @@ __global__ void transpose_square_kernel(const float *src, float *dst, uint32_t d
     if (i < d && j < d) dst[(uint64_t)j * d + i] = src[(uint64_t)i * d + j];
 }
 
-constexpr int kPrepQ = 8; // queries per block of rabitq_query_prep_kernel
+constexpr int kPrepQ = 8;       // queries per block of rabitq_query_prep_kernel
+constexpr int kPrepRows = 256;  // output rows per block
 
 // Query half of estimate_distances_batch_fast (rabitq.rs:398-420): qnorm = sqrt(sum q_j^2)
 // (sequential), qn = q / qnorm, rq[i] = sum_j rot_t[i][j] * qn[j] (rotate_query, :191-201,
-// sequential over j). One block handles kPrepQ queries so each rotation element is loaded once
-// for several queries (their component j side by side in LDS: two 16-byte reads per j); thread i
-// owns output row i (block = dim rounded up to whole waves, at most 1024 threads: the rows are the
-// parallelism). rq is left untouched for qnorm < 1e-10. Dynamic LDS: kPrepQ * dim floats.
-__global__ void __launch_bounds__(1024)
+// sequential over j). A block handles kPrepQ queries and kPrepRows output rows: each rotation element is loaded once
+// for several queries (their component j side by side in LDS: two 16-byte reads per j), thread t owns output row
+// blockIdx.y * kPrepRows + t and walks j in order with AHEAD of its (coalesced) rotation loads in flight — one
+// load per trip to memory made a lone 1536-d query wait 380 us for its rotation (64 in flight: 60 us), and the rows
+// split over blocks are what a small batch has for parallelism; a batch that fills the GPU does better with 32 and the
+// registers that saves (4096 x 768-d: 0.178 ms against 0.216). Every block of a query group computes the group's norms (a sequential sum
+// from LDS); blockIdx.y == 0 writes them. rq is left untouched for qnorm < 1e-10.
+// grid = (ceil(nq / kPrepQ), ceil(dim / kPrepRows)), block kPrepRows, dynamic LDS: kPrepQ * dim floats.
+template <int AHEAD>
+__global__ void __launch_bounds__(kPrepRows)
 rabitq_query_prep_kernel(const float *queries, const float *rot, uint32_t nq, uint32_t dim, float *rq, float *qnorm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qn = reinterpret_cast<float *>(smem); // [dim][kPrepQ]
     __shared__ float s_norm[kPrepQ];
     const uint32_t q0 = blockIdx.x * kPrepQ;
+    for (uint32_t t = threadIdx.x; t < kPrepQ * dim; t += blockDim.x) {
+        const uint32_t qq = t / dim, j = t % dim, q = q0 + qq;
+        qn[j * kPrepQ + qq] = q < nq ? queries[(uint64_t)q * dim + j] : 0.f;
+    }
+    __syncthreads();
     if (threadIdx.x < kPrepQ) {
         const uint32_t q = q0 + threadIdx.x;
         float s = 0.f;
-        if (q < nq)
-            for (uint32_t j = 0; j < dim; ++j) {
-                float x = queries[(uint64_t)q * dim + j];
-                s += x * x;
-            }
-        float nrm = sqrtf(s);
+        for (uint32_t j = 0; j < dim; ++j) {
+            const float x = qn[j * kPrepQ + threadIdx.x];
+            s += x * x;
+        }
+        const float nrm = sqrtf(s);
         s_norm[threadIdx.x] = nrm;
-        if (q < nq) qnorm[q] = nrm;
+        if (q < nq && blockIdx.y == 0) qnorm[q] = nrm;
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < kPrepQ * dim; t += blockDim.x) {
-        const uint32_t qq = t / dim, j = t % dim, q = q0 + qq;
-        qn[j * kPrepQ + qq] = (q < nq && s_norm[qq] >= 1e-10f) ? queries[(uint64_t)q * dim + j] / s_norm[qq] : 0.f;
+        const float nrm = s_norm[t % kPrepQ];
+        qn[t] = nrm >= 1e-10f ? qn[t] / nrm : 0.f;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) {
-        float acc[kPrepQ];
+    const uint32_t i = blockIdx.y * kPrepRows + threadIdx.x;
+    if (i >= dim) return; // (no barrier below)
+    float acc[kPrepQ];
 #pragma unroll
-        for (int qq = 0; qq < kPrepQ; ++qq) acc[qq] = 0.f;
-        for (uint32_t j = 0; j < dim; ++j) {
-            const float r = rot[(uint64_t)j * dim + i];
+    for (int qq = 0; qq < kPrepQ; ++qq) acc[qq] = 0.f;
+    const float *col = rot + i;
+    uint32_t j = 0;
+    for (; j + AHEAD <= dim; j += AHEAD) {
+        float r[AHEAD];
 #pragma unroll
-            for (int qq = 0; qq < kPrepQ; ++qq) acc[qq] += r * qn[j * kPrepQ + qq];
+        for (int u = 0; u < AHEAD; ++u) r[u] = col[(uint64_t)(j + u) * dim];
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+#pragma unroll
+            for (int qq = 0; qq < kPrepQ; ++qq) acc[qq] += r[u] * qn[(j + u) * kPrepQ + qq];
         }
-#pragma unroll
-        for (int qq = 0; qq < kPrepQ; ++qq)
-            if (q0 + qq < nq && s_norm[qq] >= 1e-10f) rq[(uint64_t)(q0 + qq) * dim + i] = acc[qq];
     }
+    for (; j < dim; ++j) {
+        const float r = col[(uint64_t)j * dim];
+#pragma unroll
+        for (int qq = 0; qq < kPrepQ; ++qq) acc[qq] += r * qn[j * kPrepQ + qq];
+    }
+#pragma unroll
+    for (int qq = 0; qq < kPrepQ; ++qq)
+        if (q0 + qq < nq && s_norm[qq] >= 1e-10f) rq[(uint64_t)(q0 + qq) * dim + i] = acc[qq];
 }
 
 // estimate_distance_fast (rabitq.rs:335-363) for vector i of a leaf of n vectors whose codes are
