@@ -200,6 +200,7 @@ struct Plan {
     uint32_t cstride = 0;   // candidate capacity per query (spill buffer)
     uint32_t sstride = 0;   // selection capacity per query
     uint32_t dist_cap = 0;  // candidates kept in LDS by the scan kernel
+    uint32_t *loc_key = nullptr, *rr_order = nullptr; // [qc] locality key of each query; the queries in key order (the rerank's order)
     uint32_t tcap = 0;      // 64-vector tiles per query (scan kernel)
     uint32_t scan_threads = 512; // block size of the scan kernels
     size_t scan_lds = 0;
@@ -917,6 +918,7 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     size_t o_rbs = carve(rg ? 2 * ((nnode + kPairScanChunk - 1) / kPairScanChunk + 1) * 4 : 0);
     size_t o_rit = carve(rg ? (npair / kGroupPairs + nnode + 1) * 16 : 0);
     size_t o_rod = carve(pl.leaf_grouped ? (npair / kGroupPairs + nnode + 1) * 4 : 0);
+    size_t o_lk = carve(qc * 4), o_rro = carve(qc * 4);
     if (!b) return off;
     pl.qcodes = (uint64_t *)(b + o_qcodes);
     pl.frontier[0] = (uint32_t *)(b + o_f0); pl.frontier[1] = (uint32_t *)(b + o_f1);
@@ -947,6 +949,7 @@ static size_t carve_plan(const cuddle_index *ix, Plan &pl, char *b) {
     pl.rq_cnt = (uint32_t *)(b + o_rc); pl.rq_poff = (uint32_t *)(b + o_rpf); pl.rq_ioff = (uint32_t *)(b + o_rio);
     pl.rq_bsum = (uint32_t *)(b + o_rbs); pl.rq_items = (uint32_t *)(b + o_rit);
     pl.rq_order = (uint32_t *)(b + o_rod);
+    pl.loc_key = (uint32_t *)(b + o_lk); pl.rr_order = (uint32_t *)(b + o_rro);
     return off;
 }
 
@@ -1510,10 +1513,10 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
     const bool order_items = by_leaf && (uint64_t)nq * pl.lstride >= 8ull * std::max<uint32_t>(ix->n_leaves, 1);
     uint32_t *work_bins = pl.rq_cnt + v.n_nodes + 1;
     hipLaunchKernelGGL(cand_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, pl.leaves, pl.lstride, pl.lcount, nq,
-                       pl.cand_count, by_leaf ? pl.rq_cnt : (uint32_t *)nullptr, v.n_nodes + 1 + 2 * kWorkBins);
+                       pl.cand_count, by_leaf ? pl.rq_cnt : (uint32_t *)nullptr, v.n_nodes + 1 + 2 * kWorkBins, pl.loc_key);
     hipLaunchKernelGGL(scan_tables_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, pl.leaves, pl.lstride, pl.lcount,
                        pl.cand_count, nq, pl.leaf_tables, tstride, by_leaf ? pl.rq_cnt : (uint32_t *)nullptr,
-                       reinterpret_cast<uint2 *>(pl.rq_pinfo), pl.rq_pnode, pl.rq_pslot);
+                       reinterpret_cast<uint2 *>(pl.rq_pinfo), pl.rq_pnode, pl.rq_pslot, pl.loc_key, pl.rr_order);
     if (by_leaf) { // the pairs in leaf order, cut into work items of at most 64 queries
         const uint32_t n = v.n_nodes, nb = (n + kPairScanChunk - 1) / kPairScanChunk;
         const bool self_carry = nb <= 16;
@@ -1614,11 +1617,15 @@ static cuddle_status launch_scan_select(cuddle_index *ix, const Plan &pl, uint32
     return CUDDLE_OK;
 }
 
-static cuddle_status launch_rerank(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, hipStream_t s) {
+// in_key_order: the queries are taken in the order launch_scan_select left in pl.rr_order for these nq queries.
+static cuddle_status launch_rerank(cuddle_index *ix, const Plan &pl, const float *dq, uint32_t nq, hipStream_t s,
+                                   bool in_key_order = true) {
     const IndexDev &v = ix->dev;
     launch_query_norms(ix, pl, dq, nq, s);
+    static const bool no_order = getenv("CUDDLE_RERANK_ORDER") && atoi(getenv("CUDDLE_RERANK_ORDER")) == 0; // A/B aid
     hipLaunchKernelGGL(rerank_kernel, dim3((pl.sstride + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
-                       pl.sel_pos, pl.sstride, pl.sel_count, pl.sel_dist, pl.qnorm);
+                       pl.sel_pos, pl.sstride, pl.sel_count, pl.sel_dist, pl.qnorm,
+                       in_key_order && !no_order ? pl.rr_order : (const uint32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
 }
@@ -2701,7 +2708,7 @@ extern "C" cuddle_status cuddle_shard_finish_rabitq(cuddle_index *idx, const flo
     hipLaunchKernelGGL(rq_cut_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, pl.sel_ord, pl.sstride, pl.sel_count, pl.rerank_k, thr, nq);
     HIP_TRY(hipGetLastError());
     mark(idx, s, CUDDLE_STAGE_RERANK);
-    ST_TRY(launch_rerank(idx, pl, d_queries, nq, s));
+    ST_TRY(launch_rerank(idx, pl, d_queries, nq, s, false));
     mark(idx, s, CUDDLE_STAGE_TOPK);
     ST_TRY(launch_topk(idx, pl, nq, d_out_ids, d_out_dist, d_out_count, s, d_out_order));
     mark(idx, s, -1);
@@ -2774,7 +2781,7 @@ extern "C" cuddle_status cuddle_shard_finish(cuddle_index *idx, const float *d_q
                            pl.sel_ord, pl.sstride, pl.sel_count);
     HIP_TRY(hipGetLastError());
     mark(idx, s, CUDDLE_STAGE_RERANK);
-    ST_TRY(launch_rerank(idx, pl, d_queries, nq, s));
+    ST_TRY(launch_rerank(idx, pl, d_queries, nq, s, false));
     mark(idx, s, CUDDLE_STAGE_TOPK);
     ST_TRY(launch_topk(idx, pl, nq, d_out_ids, d_out_dist, d_out_count, s, d_out_order));
     mark(idx, s, -1);

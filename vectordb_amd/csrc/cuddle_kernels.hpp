@@ -1206,7 +1206,7 @@ __device__ __forceinline__ void scan_tiles(const IndexDev &ix, const ScanLds &s,
 // zero != null: the launch also clears zero[0 .. n_zero) (the per-leaf pair counters scan_tables_kernel fills next).
 __global__ void __launch_bounds__(256)
 cand_count_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const uint32_t *lcount, uint32_t nq,
-                  uint32_t *cand_count, uint32_t *zero = nullptr, uint32_t n_zero = 0) {
+                  uint32_t *cand_count, uint32_t *zero = nullptr, uint32_t n_zero = 0, uint32_t *loc_key = nullptr) {
     if (zero)
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += gridDim.x * blockDim.x) zero[i] = 0;
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1219,7 +1219,12 @@ cand_count_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const u
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if (lane == 0) cand_count[q] = c;
+    if (lane == 0) {
+        cand_count[q] = c;
+        // where the query's first leaf lies in the leaf-contiguous arrays: queries with neighbouring keys read
+        // neighbouring rows (see scan_tables_kernel's rr_order)
+        if (loc_key) loc_key[q] = nl ? ix.vec_off[leaves[(uint64_t)q * lstride]] : 0xFFFFFFFFu;
+    }
 }
 
 // What a scan block needs to know about its query, prepared where every query of the batch is in
@@ -1234,26 +1239,38 @@ cand_count_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const u
 //          the total) | the leaf's code offset. Row 0 ends with the header: [tstride - 2] = q,
 //          [tstride - 1] = nl.
 // pair_cnt != null: also one (query, leaf) pair per non-empty slot, counted per leaf (see leaf_hamming_kernel).
+// loc_key != null: rr_order[r] = the query ranked r-th by loc_key (ties by query number): the order in which the rerank
+//          takes the queries, so that blocks in flight together gather rows of the same leaves (a batch of 10 000 on
+//          1M x 128-d reaches every leaf a hundred times over: 1.28 -> 1.07 ms with its queries in this order).
 __global__ void __launch_bounds__(256)
 scan_tables_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const uint32_t *lcount, const uint32_t *cand_count,
                    uint32_t nq, uint32_t *tables, uint32_t tstride, uint32_t *pair_cnt = nullptr, uint2 *pair_info = nullptr,
-                   uint32_t *pair_node = nullptr, uint32_t *pair_place = nullptr) {
+                   uint32_t *pair_node = nullptr, uint32_t *pair_place = nullptr, const uint32_t *loc_key = nullptr,
+                   uint32_t *rr_order = nullptr) {
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq) return;
-    const uint32_t mine = cand_count[q];
-    uint32_t before = 0;
+    const uint32_t mine = cand_count[q], mykey = loc_key ? loc_key[q] : 0u;
+    uint32_t before = 0, kbefore = 0;
     for (uint32_t j0 = lane; j0 < nq; j0 += 64 * 8) { // eight loads in flight per lane (nq >= 1: q < nq)
-        uint32_t c[8];
+        uint32_t c[8], lk[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] = cand_count[min(j0 + 64 * u, nq - 1)];
+        for (int u = 0; u < 8; ++u) {
+            c[u] = cand_count[min(j0 + 64 * u, nq - 1)];
+            lk[u] = loc_key ? loc_key[min(j0 + 64 * u, nq - 1)] : 0u;
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const uint32_t j = j0 + 64 * u;
             before += (j < nq && (c[u] > mine || (c[u] == mine && j < q))) ? 1u : 0u;
+            kbefore += (j < nq && (lk[u] < mykey || (lk[u] == mykey && j < q))) ? 1u : 0u;
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    for (int o = 32; o > 0; o >>= 1) {
+        before += __shfl_xor(before, o, 64);
+        kbefore += __shfl_xor(kbefore, o, 64);
+    }
+    if (loc_key && lane == 0) rr_order[kbefore] = q;
     const uint32_t nl = min(lcount[q], lstride);
     uint32_t *tb = tables + (uint64_t)before * 4 * tstride;
     uint32_t run_c = 0, run_t = 0;
@@ -1791,10 +1808,10 @@ scan_all_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *lea
 #endif
 __global__ void __launch_bounds__(256, CUDDLE_RERANK_W)
 rerank_kernel(IndexDev ix, const float *queries, const uint32_t *sel_pos, uint32_t sel_stride,
-              const uint32_t *sel_count, float *sel_dist, const float *qnorm) {
+              const uint32_t *sel_count, float *sel_dist, const float *qnorm, const uint32_t *order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);
-    const uint32_t q = blockIdx.y;
+    const uint32_t q = order ? order[blockIdx.y] : blockIdx.y; // order: a permutation of the queries (scan_tables_kernel's rr_order)
     const uint32_t n = sel_count[q];
     if (blockIdx.x * 64 >= n) return;
     CUDDLE_STAMP_AT(11, 0, blockIdx.y * gridDim.x + blockIdx.x);
