@@ -10,3 +10,5 @@ run CUDDLE_X=0 python -u tools/random_parity_sweep.py --cases 50 --seed 307
 run CUDDLE_X=0 python -u tools/random_parity_sweep.py --cases 40 --seed 308 --trees
 run CUDDLE_X=0 python -u tools/random_parity_sweep.py --cases 30 --seed 309 --sharded
 run CUDDLE_X=0 python -u tools/random_parity_sweep.py --cases 30 --seed 310 --boundary
+run CUDDLE_LDS_DIST_BYTES=700 python -u tools/random_parity_sweep.py --cases 40 --seed 311
+run CUDDLE_LDS_DIST_BYTES=700 python -u tools/random_parity_sweep.py --cases 30 --seed 312 --trees
