@@ -1811,16 +1811,26 @@ rerank_kernel(IndexDev ix, const float *queries, const uint32_t *sel_pos, uint32
               const uint32_t *sel_count, float *sel_dist, const float *qnorm, const uint32_t *order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);
-    const uint32_t q = order ? order[blockIdx.y] : blockIdx.y; // order: a permutation of the queries (scan_tables_kernel's rr_order)
+    // order: a permutation of the queries (scan_tables_kernel's rr_order: neighbours reach the same leaves). Workgroups go
+    // to the 8 XCDs in turn by their linear number, and every XCD has an L2 of its own: XCD x takes the x-th eighth of
+    // the order, so that the queries that share leaves share an L2
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (order) {
+        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x, per = (gridDim.y + 7) >> 3, slot = lin >> 3;
+        by = (lin & 7) * per + slot / gridDim.x;
+        bx = slot % gridDim.x;
+        if (by >= gridDim.y) return;
+    }
+    const uint32_t q = order ? order[by] : by;
     const uint32_t n = sel_count[q];
-    if (blockIdx.x * 64 >= n) return;
+    if (bx * 64 >= n) return;
     CUDDLE_STAMP_AT(11, 0, blockIdx.y * gridDim.x + blockIdx.x);
     const uint32_t D = ix.dim;
     const float *qg = queries + (uint64_t)q * D;
     for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) qs[i] = qg[i];
     __syncthreads();
     CUDDLE_STAMP_AT(11, 1, blockIdx.y * gridDim.x + blockIdx.x);
-    const uint32_t j = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    const uint32_t j = bx * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
     // a group past the selection does nothing: its four lanes leave together, so the quad exchanges of the groups
     // that stay are among active lanes only (and it reads no row)
     if (j >= n) return;
