@@ -1623,9 +1623,9 @@ static cuddle_status launch_rerank(cuddle_index *ix, const Plan &pl, const float
     const IndexDev &v = ix->dev;
     launch_query_norms(ix, pl, dq, nq, s);
     static const bool no_order = getenv("CUDDLE_RERANK_ORDER") && atoi(getenv("CUDDLE_RERANK_ORDER")) == 0; // A/B aid
-    hipLaunchKernelGGL(rerank_kernel, dim3((pl.sstride + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
-                       pl.sel_pos, pl.sstride, pl.sel_count, pl.sel_dist, pl.qnorm,
-                       in_key_order && !no_order ? pl.rr_order : (const uint32_t *)nullptr);
+    const uint32_t *order = in_key_order && !no_order ? pl.rr_order : nullptr;
+    hipLaunchKernelGGL(rerank_kernel, dim3((pl.sstride + 63) / 64, order ? (nq + 7) & ~7u : nq), dim3(256), v.dim * sizeof(float), s, v, dq,
+                       pl.sel_pos, pl.sstride, pl.sel_count, pl.sel_dist, pl.qnorm, order, nq);
     HIP_TRY(hipGetLastError());
     return CUDDLE_OK;
 }

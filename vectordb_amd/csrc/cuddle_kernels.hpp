@@ -1802,25 +1802,26 @@ scan_all_hamming_kernel(IndexDev ix, const uint64_t *qcodes, const uint32_t *lea
 // distance(query, full_vectors.get(idx), metric) for every selected candidate. grid =
 // (ceil(sel_stride/64), nq), block 256: the query is staged in LDS once per block, each 4-lane
 // group streams one candidate row with 128-bit loads (64 contiguous bytes per group and step).
+// order != null: grid = (ceil(sel_stride/64), nq rounded up to a multiple of 8).
 #ifndef CUDDLE_RERANK_U
 #define CUDDLE_RERANK_U 8
 #define CUDDLE_RERANK_W 8
 #endif
 __global__ void __launch_bounds__(256, CUDDLE_RERANK_W)
 rerank_kernel(IndexDev ix, const float *queries, const uint32_t *sel_pos, uint32_t sel_stride,
-              const uint32_t *sel_count, float *sel_dist, const float *qnorm, const uint32_t *order) {
+              const uint32_t *sel_count, float *sel_dist, const float *qnorm, const uint32_t *order, uint32_t nq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);
     // order: a permutation of the queries (scan_tables_kernel's rr_order: neighbours reach the same leaves). Workgroups go
     // to the 8 XCDs in turn by their linear number, and every XCD has an L2 of its own: XCD x takes the x-th eighth of
     // the order, so that the queries that share leaves share an L2
     uint32_t bx = blockIdx.x, by = blockIdx.y;
-    if (order) {
-        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x, per = (gridDim.y + 7) >> 3, slot = lin >> 3;
+    if (order) { // gridDim.y = nq rounded up to a multiple of 8: every XCD has gridDim.y / 8 places, of which the last may be empty
+        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x, per = gridDim.y >> 3, slot = lin >> 3;
         by = (lin & 7) * per + slot / gridDim.x;
         bx = slot % gridDim.x;
-        if (by >= gridDim.y) return;
     }
+    if (by >= nq) return;
     const uint32_t q = order ? order[by] : by;
     const uint32_t n = sel_count[q];
     if (bx * 64 >= n) return;
