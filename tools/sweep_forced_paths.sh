@@ -12,3 +12,5 @@ run CUDDLE_X=0 python -u tools/random_parity_sweep.py --cases 30 --seed 309 --sh
 run CUDDLE_X=0 python -u tools/random_parity_sweep.py --cases 30 --seed 310 --boundary
 run CUDDLE_LDS_DIST_BYTES=700 python -u tools/random_parity_sweep.py --cases 40 --seed 311
 run CUDDLE_LDS_DIST_BYTES=700 python -u tools/random_parity_sweep.py --cases 30 --seed 312 --trees
+run CUDDLE_SCAN_ORDER=1 python -u tools/random_parity_sweep.py --cases 40 --seed 313
+run CUDDLE_SCAN_ORDER=1 python -u tools/random_parity_sweep.py --cases 30 --seed 314 --sharded

@@ -1246,7 +1246,7 @@ __global__ void __launch_bounds__(256)
 scan_tables_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const uint32_t *lcount, const uint32_t *cand_count,
                    uint32_t nq, uint32_t *tables, uint32_t tstride, uint32_t *pair_cnt = nullptr, uint2 *pair_info = nullptr,
                    uint32_t *pair_node = nullptr, uint32_t *pair_place = nullptr, const uint32_t *loc_key = nullptr,
-                   uint32_t *rr_order = nullptr) {
+                   uint32_t *rr_order = nullptr, uint32_t tables_by_key = 0) {
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq) return;
     const uint32_t mine = cand_count[q], mykey = loc_key ? loc_key[q] : 0u;
@@ -1271,6 +1271,17 @@ scan_tables_kernel(IndexDev ix, const uint32_t *leaves, uint32_t lstride, const 
         kbefore += __shfl_xor(kbefore, o, 64);
     }
     if (loc_key && lane == 0) rr_order[kbefore] = q;
+    if (tables_by_key) {
+        // the scan blocks in key order instead, XCD by XCD: block b runs on XCD b % 8, which takes the next run of
+        // the order (as many queries as there are blocks b < nq with b % 8 == x)
+        uint32_t r = kbefore, x = 0;
+        for (; x < 7; ++x) {
+            const uint32_t cnt = (nq - x + 7) >> 3;
+            if (r < cnt) break;
+            r -= cnt;
+        }
+        before = r * 8 + x;
+    }
     const uint32_t nl = min(lcount[q], lstride);
     uint32_t *tb = tables + (uint64_t)before * 4 * tstride;
     uint32_t run_c = 0, run_t = 0;
