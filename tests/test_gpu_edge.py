@@ -307,3 +307,28 @@ def test_selection_larger_than_the_index(gpu):
         q = queries_like(x, 5, 4)
         _compare_full(fi, dev, q, 3000, 6, 1000, _ffi.SEARCH_STATS_VARIANT)
         _compare_full(fi, dev, q, 3000, 1000, 1000, _ffi.SEARCH_STATS_VARIANT)
+
+
+@pytest.mark.parametrize("code_kind", ["binary", "rabitq"])
+@pytest.mark.parametrize("nq", [1, 7, 13, 203])
+def test_block_orders_and_lds_sizes_give_the_same_answers(gpu, monkeypatch, code_kind, nq):
+    """The order in which the scan and the rerank take the queries (by work, or by the place of each query's first leaf
+    with an eighth of that order per XCD: batches that are not multiples of 8 leave places empty) and the size of the
+    scan's LDS distance array (queries beyond it keep their distances in global memory) are performance choices: every
+    combination must give the oracle's answers."""
+    x, fi = small_index(n=4000, d=24, n_clusters=30, branching=6, leaf=25, code_kind=code_kind)
+    dev = DeviceIndex(fi, gpu)
+    q = queries_like(x, nq, 17)
+    base = dev.search_batch(q, 8, 5, 6)
+    oi = _oracle().OracleIndex(fi)
+    for i in range(0, nq, max(1, nq // 9)):
+        r = oi.search(q[i], 8, 5, 6)
+        assert np.array_equal(base[0][i, :r["count"]], r["ids"][:r["count"]]) and base[2][i] == r["count"]
+    for env in ({"CUDDLE_SCAN_ORDER": "1"}, {"CUDDLE_SCAN_ORDER": "0"}, {"CUDDLE_LDS_DIST_BYTES": "300"},
+                {"CUDDLE_SCAN_ORDER": "1", "CUDDLE_LDS_DIST_BYTES": "300"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = DeviceIndex(fi, gpu).search_batch(q, 8, 5, 6)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert all(np.array_equal(a, b) for a, b in zip(base, got)), env
