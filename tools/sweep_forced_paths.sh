@@ -14,3 +14,5 @@ run CUDDLE_LDS_DIST_BYTES=700 python -u tools/random_parity_sweep.py --cases 40 
 run CUDDLE_LDS_DIST_BYTES=700 python -u tools/random_parity_sweep.py --cases 30 --seed 312 --trees
 run CUDDLE_SCAN_ORDER=1 python -u tools/random_parity_sweep.py --cases 40 --seed 313
 run CUDDLE_SCAN_ORDER=1 python -u tools/random_parity_sweep.py --cases 30 --seed 314 --sharded
+run CUDDLE_REFINE_BUCKETS=1 python -u tools/random_parity_sweep.py --cases 40 --seed 315
+run CUDDLE_REFINE_BUCKETS=2 python -u tools/random_parity_sweep.py --cases 30 --seed 316 --trees

@@ -1408,9 +1408,17 @@ static cuddle_status launch_route(cuddle_index *ix, const Plan &pl, const float 
             else
                 hipLaunchKernelGGL(route_prefilter_kernel, dim3(nq), dim3(256), 0, s, pl.fdist, pl.fstride, n, kc, pl.rc_pos,
                                    pl.kc_cap, pl.rc_max);
-            hipLaunchKernelGGL(route_refine_kernel, dim3((kc + 63) / 64, nq), dim3(256), v.dim * sizeof(float), s, v, dq,
+            // (candidates by eighths of the level, an eighth per XCD: see the kernel; worth it once the level's rows are
+            // more than one L2 holds anyway)
+            static const int bucket_env = getenv("CUDDLE_REFINE_BUCKETS") ? atoi(getenv("CUDDLE_REFINE_BUCKETS")) : -1; // A/B aid: 0 off, Z
+            const uint64_t table_bytes = (uint64_t)n * v.dim * 4;
+            const bool buckets = bucket_env != 0 && n >= 512 && (bucket_env > 0 || (v.dim >= 512 && table_bytes > (16ull << 20)));
+            const uint32_t bz = bucket_env > 0 ? (uint32_t)bucket_env : 1; // (parts of an eighth, one after the other: 2 and 4 measured slower)
+            hipLaunchKernelGGL(route_refine_kernel, dim3(buckets ? 8 : (kc + 63) / 64, nq, buckets ? bz : 1), dim3(256),
+                               (((size_t)v.dim + 3) & ~(size_t)3) * sizeof(float) + (buckets ? (size_t)kc * 4 : 0), s, v, dq,
                                g.nodes, pl.rc_pos, pl.kc_cap, kc, pl.rc_dist, pl.qnorm, 0u, (const uint32_t *)nullptr,
-                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, zero_cnt, (ix->level_width[l] << po.shift) + 1);
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, zero_cnt, (ix->level_width[l] << po.shift) + 1,
+                               buckets ? (n + 8 * bz - 1) / (8 * bz) : 0u);
             hipLaunchKernelGGL(route_finish_kernel, dim3(nq), dim3(256), route_finish_lds_bytes(host_next_pow2(kc), pl.probes), s,
                                v, g.nodes, n, pl.rc_pos, pl.rc_dist, pl.kc_cap, kc, pl.rc_max, pl.qsq, g.max_sqn, pl.probes,
                                pl.frontier[cur ^ 1], pl.fstride, pl.fcount[cur ^ 1], pl.leaves, pl.lstride, pl.lcount,

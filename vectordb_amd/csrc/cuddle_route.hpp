@@ -1881,14 +1881,15 @@ __global__ void __launch_bounds__(256)
 route_refine_kernel(IndexDev ix, const float *queries, const uint32_t *level_nodes, const uint32_t *cand_pos,
                     uint32_t cstride, uint32_t kc, float *cand_dist, const float *qnorm, uint32_t fstride = 0,
                     const uint32_t *skip = nullptr, const uint32_t *cand_cnt = nullptr, const uint32_t *seg = nullptr,
-                    uint32_t pstride = 0, uint32_t *zero = nullptr, uint32_t n_zero = 0) {
+                    uint32_t pstride = 0, uint32_t *zero = nullptr, uint32_t n_zero = 0, uint32_t bucket_div = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qs = reinterpret_cast<float *>(smem);
-    uint32_t *st = reinterpret_cast<uint32_t *>(qs + ((ix.dim + 3) & ~3u)); // the query's segment table (seg != null)
+    uint32_t *st = reinterpret_cast<uint32_t *>(qs + ((ix.dim + 3) & ~3u)); // the query's segment table (seg != null), or the block's candidates (bucket_div != 0)
     const uint32_t q = blockIdx.y, D = ix.dim;
     if (zero) { // the pair counters the level's finish kernel fills next (instead of a memset launch of their own)
-        const uint32_t nt = gridDim.x * gridDim.y * blockDim.x;
-        for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n_zero; i += nt) zero[i] = 0;
+        const uint32_t nt = gridDim.x * gridDim.y * blockDim.x; // (the blocks of z == 0 are enough)
+        if (blockIdx.z == 0)
+            for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n_zero; i += nt) zero[i] = 0;
     }
     if (skip && skip[q]) return;
     if (cand_cnt) { // per-query frontiers: level_nodes is the array of frontiers, fstride nodes per query
@@ -1900,6 +1901,27 @@ route_refine_kernel(IndexDev ix, const float *queries, const uint32_t *level_nod
     for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) qs[i] = qg[i];
     if (seg)
         for (uint32_t i = threadIdx.x; i < seg_stride(pstride); i += blockDim.x) st[i] = seg[(uint64_t)q * seg_stride(pstride) + i];
+    if (bucket_div) {
+        // Shared level, grid (8, nq, Z): block (x, q, z) takes the query's candidates in the z-th part of the x-th eighth
+        // of the level (bucket_div nodes per part). Workgroups go to the 8 XCDs in turn by linear number, so the blocks
+        // x run on XCD x, whose L2 then serves one eighth of the level's centroid rows to every query of the batch
+        // instead of a share of all of them - and, z being the slowest grid dimension, one part of the eighth at a time
+        // (Z is chosen so that a part fits the L2). Each block looks through the query's candidate list for its own.
+        __shared__ uint32_t n_mine;
+        if (threadIdx.x == 0) n_mine = 0;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < kc; j += blockDim.x)
+            if (cand_pos[(uint64_t)q * cstride + j] / bucket_div == blockIdx.x * gridDim.z + blockIdx.z) st[atomicAdd(&n_mine, 1u)] = j;
+        __syncthreads();
+        const uint32_t cnt = n_mine, sub = threadIdx.x & 3;
+        for (uint32_t e = threadIdx.x >> 2; e < cnt; e += blockDim.x >> 2) { // (whole 4-lane groups leave: see rerank_kernel)
+            const uint32_t j = st[e], node = level_nodes[cand_pos[(uint64_t)q * cstride + j]];
+            const float d = distance_group4_qn(qs, ix.centroids + (uint64_t)node * D, D, ix.metric, sub, (D & 3) == 0,
+                                               ix.metric == kMetricCosine ? qnorm[q] : 0.f);
+            if (sub == 0) cand_dist[(uint64_t)q * cstride + j] = d;
+        }
+        return;
+    }
     __syncthreads();
     const uint32_t j = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
     if (j >= kc) return; // (whole 4-lane groups leave: see rerank_kernel)
